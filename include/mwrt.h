@@ -1,0 +1,153 @@
+/*
+ * mwrt.h -- C ABI of the MI355X-native line-by-line microwave forward operator.
+ *
+ * Drop-in boundary for ONE path of apschera2023uzk/MWR_fast_forward_operators_and_LBLs:
+ * the pyrtlib LBL call made by python_src/proc/PyRTlib_processing.py:123-127
+ *
+ *     rte = TbCloudRTE(z[::-1], p[::-1], t[::-1], rh[::-1], frqs, ang)   (:123)
+ *     rte.init_absmdl(mdl)                                               (:124)
+ *     rte.satellite = False                                              (:125)
+ *     df = rte.execute(); tbs[i,:,k,j] = df["tbtotal"].values            (:126-127)
+ *
+ * The reference has no FFI layer of its own: these entry points are
+ * what a ctypes stub placed behind that Python call surface binds.
+ * Plain pointers and sizes only; the library never throws across the boundary; every
+ * function returns an mwrt_status (0 = ok, <0 = error, text via mwrt_last_error()).
+ *
+ * Array conventions (all float64, C-contiguous, caller-owned):
+ *   profiles   [nprof][nlev], level 0 = ground, level nlev-1 = top -- what TbCloudRTE sees
+ *              after the wrapper's [::-1] (:123); z in km, p in hPa, T in K, rh as fraction
+ *              (:109-114).
+ *   frq_ghz    [nf]    (:87-88)
+ *   elev_deg   [nang]  ELEVATION angles, 90 = zenith (:106, :37)
+ *   tb_out     [nprof][nang][nf]  == pyrtlib's DataFrame row order (angle-major) per profile
+ *   valid_out  [nprof] 1 = ok; 0 = NaN in the inputs of that profile (the wrapper's
+ *              check_for_nans, :71-79, :117-119: outputs stay NaN); 2 = negative absorption
+ *              met in the layer integration (pyrtlib raises ValueError there).
+ */
+#ifndef MWRT_H
+#define MWRT_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MWRT_VERSION 100          /* 0.1.0 */
+#define MWRT_MAX_H2O_LINES 32
+#define MWRT_MAX_O2_LINES 64
+#define MWRT_MAX_LEVELS 1024      /* one lane per level, one workgroup per profile */
+#define MWRT_MAX_ANGLES 64
+
+typedef enum {
+  MWRT_OK = 0,
+  MWRT_ERR_INVALID_ARGUMENT = -1,
+  MWRT_ERR_NO_DEVICE = -2,
+  MWRT_ERR_HIP = -3,
+  MWRT_ERR_OUT_OF_MEMORY = -4,
+  MWRT_ERR_UNSUPPORTED = -5
+} mwrt_status;
+
+/* Replaces pyrtlib's process-global model state set by init_absmdl(str) (:124): an explicit,
+ * immutable table record.  Field-for-field image of spectroscopy.ModelTables (Python host). */
+typedef struct mwrt_model_desc {
+  int32_t n_h2o, n_o2;
+  int32_t h2o_shift_mode;   /* 0 none (R98); 2 air+self shift with ln-T coefficients (R17+) */
+  int32_t o2_mix_mode;      /* 0 first order on total pressure (R98/R17); 1 second order on den (R19+) */
+  int32_t o2_line1_dens;    /* R98: 118.75-GHz width uses DENS */
+  int32_t n2_fdep;          /* absn2 frequency-dependence factor on/off */
+  int32_t n2_ptot;          /* 1: N2 at total pressure (pre-2019, folded into the O2 routine) */
+  int32_t reserved0;
+  double h2o_reftcon, h2o_reftline, h2o_cf, h2o_xcf, h2o_cs, h2o_xcs, h2o_pvap_div, h2o_den_coef;
+  double o2_x, o2_wb300, o2_pvap_div, o2_wv_factor, o2_nonres, o2_coef;
+  double n2_l, n2_m, n2_n;
+  double t_cosmic, planck_h, boltzmann_k;
+  double h2o_fl[MWRT_MAX_H2O_LINES], h2o_s1[MWRT_MAX_H2O_LINES], h2o_b2[MWRT_MAX_H2O_LINES];
+  double h2o_w0[MWRT_MAX_H2O_LINES], h2o_x[MWRT_MAX_H2O_LINES];
+  double h2o_w0s[MWRT_MAX_H2O_LINES], h2o_xs[MWRT_MAX_H2O_LINES];
+  double h2o_sh[MWRT_MAX_H2O_LINES], h2o_xh[MWRT_MAX_H2O_LINES];
+  double h2o_shs[MWRT_MAX_H2O_LINES], h2o_xhs[MWRT_MAX_H2O_LINES];
+  double h2o_aair[MWRT_MAX_H2O_LINES], h2o_aself[MWRT_MAX_H2O_LINES];
+  double h2o_w2[MWRT_MAX_H2O_LINES], h2o_xw2[MWRT_MAX_H2O_LINES];
+  double h2o_w2s[MWRT_MAX_H2O_LINES], h2o_xw2s[MWRT_MAX_H2O_LINES];
+  double h2o_d2[MWRT_MAX_H2O_LINES], h2o_d2s[MWRT_MAX_H2O_LINES];
+  double o2_f[MWRT_MAX_O2_LINES], o2_s300[MWRT_MAX_O2_LINES], o2_be[MWRT_MAX_O2_LINES];
+  double o2_w300[MWRT_MAX_O2_LINES], o2_y0[MWRT_MAX_O2_LINES], o2_y1[MWRT_MAX_O2_LINES];
+  double o2_g0[MWRT_MAX_O2_LINES], o2_g1[MWRT_MAX_O2_LINES];
+  double o2_dnu0[MWRT_MAX_O2_LINES], o2_dnu1[MWRT_MAX_O2_LINES];
+} mwrt_model_desc;
+
+/* Optional by-products of execute() (the other DataFrame columns pyrtlib returns; the
+ * reference reads only "tbtotal", :127).  Any pointer may be NULL. */
+typedef struct mwrt_tb_extras {
+  double* tbatm;    /* [nprof][nang][nf] */
+  double* tmr;      /* [nprof][nang][nf] */
+  double* tauwet;   /* [nprof][nang][nf] slant-path opacity, Np */
+  double* taudry;   /* [nprof][nang][nf] */
+  double* taulay;   /* [nprof][nf][nlev] ZENITH layer optical depth (wet+dry), entry 0 = 0 */
+} mwrt_tb_extras;
+
+typedef struct mwrt_context mwrt_context;   /* one per (host thread, GPU): device, stream, workspace */
+typedef struct mwrt_model mwrt_model;       /* device-resident copy of an mwrt_model_desc */
+
+int mwrt_version(void);
+/* sizeof(mwrt_model_desc) as compiled into the library (binding self-check). */
+size_t mwrt_model_desc_size(void);
+/* Number of usable HIP devices; 0 when there is no GPU / driver (never an error). */
+int mwrt_device_count(void);
+/* Thread-local text of the last failure on this thread ("" if none). */
+const char* mwrt_last_error(void);
+
+int mwrt_create(int device_id, mwrt_context** out);
+int mwrt_destroy(mwrt_context* ctx);
+int mwrt_model_create(mwrt_context* ctx, const mwrt_model_desc* desc, mwrt_model** out);
+int mwrt_model_destroy(mwrt_context* ctx, mwrt_model* model);
+
+/* TbCloudRTE(...).execute() for a batch of profiles; HOST buffers, synchronous.
+ * Replaces the triple loop + 4 x execute() of PyRTlib_processing.py:99-151 for one model. */
+int mwrt_tb_batch(mwrt_context* ctx, const mwrt_model* model,
+                  int64_t nprof, int32_t nlev,
+                  const double* z_km, const double* p_hpa, const double* t_k, const double* rh_frac,
+                  int32_t nf, const double* frq_ghz,
+                  int32_t nang, const double* elev_deg,
+                  double* tb_out, uint8_t* valid_out, const mwrt_tb_extras* extras);
+
+/* Same, on DEVICE buffers (profiles, tb_out, valid_out and the extras already in HBM),
+ * asynchronous on `stream` (a hipStream_t; NULL = the context's own stream).  frq_ghz and
+ * elev_deg stay small host arrays.  This is the entry bench.py times. */
+int mwrt_tb_batch_device(mwrt_context* ctx, const mwrt_model* model,
+                         int64_t nprof, int32_t nlev,
+                         const double* d_z_km, const double* d_p_hpa, const double* d_t_k,
+                         const double* d_rh_frac,
+                         int32_t nf, const double* frq_ghz,
+                         int32_t nang, const double* elev_deg,
+                         double* d_tb_out, uint8_t* d_valid_out, const mwrt_tb_extras* d_extras,
+                         void* stream);
+
+/* RTEquation.clearsky_absorption for a batch: awet, adry [nprof][nf][nlev] in Np/km
+ * (exposes kernel K1 alone, for parity tests and the roofline measurement). HOST buffers. */
+int mwrt_absorption_batch(mwrt_context* ctx, const mwrt_model* model,
+                          int64_t nprof, int32_t nlev,
+                          const double* p_hpa, const double* t_k, const double* rh_frac,
+                          int32_t nf, const double* frq_ghz,
+                          double* awet_out, double* adry_out);
+int mwrt_absorption_batch_device(mwrt_context* ctx, const mwrt_model* model,
+                                 int64_t nprof, int32_t nlev,
+                                 const double* d_p_hpa, const double* d_t_k, const double* d_rh_frac,
+                                 int32_t nf, const double* frq_ghz,
+                                 double* d_awet_out, double* d_adry_out, void* stream);
+
+/* Block until everything queued on the context's stream (or `stream`) has finished. */
+int mwrt_synchronize(mwrt_context* ctx, void* stream);
+
+/* Average device time, in milliseconds, of the last timed launch on this context:
+ * mwrt_set_timing(ctx, 1) brackets every kernel launch with hipEvents on the launch stream. */
+int mwrt_set_timing(mwrt_context* ctx, int enabled);
+int mwrt_last_kernel_ms(mwrt_context* ctx, double* ms_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MWRT_H */

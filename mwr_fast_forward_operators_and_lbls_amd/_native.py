@@ -1,0 +1,230 @@
+"""ctypes binding of libmwrt.so (include/mwrt.h).  No fallback: if the HIP library or a GPU is
+missing every compute entry point raises -- the product never routes through a CPU path."""
+from __future__ import annotations
+
+import ctypes
+import os
+import threading
+from typing import Dict, Optional
+
+import numpy as np
+
+from .spectroscopy import ModelTables, MwrtModelDesc, get_model
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmwrt.so")
+
+c_double_p = ctypes.POINTER(ctypes.c_double)
+c_uint8_p = ctypes.POINTER(ctypes.c_uint8)
+
+
+class MwrtError(RuntimeError):
+    """A non-zero mwrt_status came back across the C ABI."""
+
+    def __init__(self, code: int, where: str, text: str):
+        super().__init__(f"{where} failed with status {code}: {text}")
+        self.code = code
+
+
+class NativeLibraryMissing(ImportError):
+    pass
+
+
+class MwrtTbExtras(ctypes.Structure):
+    _fields_ = [("tbatm", ctypes.c_void_p), ("tmr", ctypes.c_void_p), ("tauwet", ctypes.c_void_p),
+                ("taudry", ctypes.c_void_p), ("taulay", ctypes.c_void_p)]
+
+
+#: every symbol include/mwrt.h declares: (name, restype, argtypes)
+_i32, _i64, _vp = ctypes.c_int32, ctypes.c_int64, ctypes.c_void_p
+SIGNATURES = {
+    "mwrt_version": (ctypes.c_int, []),
+    "mwrt_model_desc_size": (ctypes.c_size_t, []),
+    "mwrt_device_count": (ctypes.c_int, []),
+    "mwrt_last_error": (ctypes.c_char_p, []),
+    "mwrt_create": (ctypes.c_int, [ctypes.c_int, ctypes.POINTER(_vp)]),
+    "mwrt_destroy": (ctypes.c_int, [_vp]),
+    "mwrt_model_create": (ctypes.c_int, [_vp, ctypes.POINTER(MwrtModelDesc), ctypes.POINTER(_vp)]),
+    "mwrt_model_destroy": (ctypes.c_int, [_vp, _vp]),
+    "mwrt_tb_batch": (ctypes.c_int, [_vp, _vp, _i64, _i32, _vp, _vp, _vp, _vp, _i32, _vp, _i32, _vp,
+                                     _vp, _vp, ctypes.POINTER(MwrtTbExtras)]),
+    "mwrt_tb_batch_device": (ctypes.c_int, [_vp, _vp, _i64, _i32, _vp, _vp, _vp, _vp, _i32, _vp, _i32, _vp,
+                                            _vp, _vp, ctypes.POINTER(MwrtTbExtras), _vp]),
+    "mwrt_absorption_batch": (ctypes.c_int, [_vp, _vp, _i64, _i32, _vp, _vp, _vp, _i32, _vp, _vp, _vp]),
+    "mwrt_absorption_batch_device": (ctypes.c_int, [_vp, _vp, _i64, _i32, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp]),
+    "mwrt_synchronize": (ctypes.c_int, [_vp, _vp]),
+    "mwrt_set_timing": (ctypes.c_int, [_vp, ctypes.c_int]),
+    "mwrt_last_kernel_ms": (ctypes.c_int, [_vp, ctypes.POINTER(ctypes.c_double)]),
+}
+
+_lib = None
+_lib_lock = threading.Lock()
+
+
+def load_library(path: Optional[str] = None) -> ctypes.CDLL:
+    """dlopen libmwrt.so and type every entry point.  Raises NativeLibraryMissing if absent."""
+    global _lib
+    with _lib_lock:
+        if _lib is not None and path is None:
+            return _lib
+        p = path or LIB_PATH
+        if not os.path.exists(p):
+            raise NativeLibraryMissing(
+                f"{p} not built: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(hipcc --offload-arch=gfx950). There is no CPU fallback.")
+        lib = ctypes.CDLL(p)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(lib, name)
+            fn.restype, fn.argtypes = res, args
+        if lib.mwrt_model_desc_size() != ctypes.sizeof(MwrtModelDesc):
+            raise NativeLibraryMissing("mwrt_model_desc layout mismatch between libmwrt.so and spectroscopy.py")
+        if path is None:
+            _lib = lib
+        return lib
+
+
+def device_count() -> int:
+    return int(load_library().mwrt_device_count())
+
+
+def _f64(a, shape=None, name="array"):
+    """Contiguous float64 copy/view; resolves the negative-stride views the wrapper passes
+    (z_in[::-1], PyRTlib_processing.py:123)."""
+    x = np.ascontiguousarray(a, dtype=np.float64)
+    if shape is not None and x.shape != tuple(shape):
+        raise ValueError(f"{name}: expected shape {tuple(shape)}, got {x.shape}")
+    return x
+
+
+def _ptr(x):
+    return x.ctypes.data_as(ctypes.c_void_p) if isinstance(x, np.ndarray) else ctypes.c_void_p(int(x))
+
+
+class Context:
+    """One (host thread, GPU) pair: HIP stream + workspace + cached model tables."""
+
+    def __init__(self, device_id: int = 0):
+        self._lib = load_library()
+        h = ctypes.c_void_p()
+        self._handle = None
+        self._check(self._lib.mwrt_create(int(device_id), ctypes.byref(h)), "mwrt_create")
+        self._handle = h
+        self.device_id = int(device_id)
+        self._models: Dict[str, ctypes.c_void_p] = {}
+        self._model_tables: Dict[str, ModelTables] = {}
+
+    # -- plumbing ---------------------------------------------------------------------------
+    def _check(self, rc: int, where: str):
+        if rc != 0:
+            raise MwrtError(rc, where, self._lib.mwrt_last_error().decode("utf-8", "replace"))
+
+    def close(self):
+        if getattr(self, "_handle", None):
+            for m in self._models.values():
+                self._lib.mwrt_model_destroy(self._handle, m)
+            self._models.clear()
+            self._lib.mwrt_destroy(self._handle)
+            self._handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def model(self, model) -> ctypes.c_void_p:
+        """Device-resident tables for a model name or a ModelTables record (cached per context)."""
+        tables = get_model(model) if isinstance(model, str) else model
+        key = tables.name
+        if key in self._models and self._model_tables[key] is tables:
+            return self._models[key]
+        if key in self._models:
+            self._lib.mwrt_model_destroy(self._handle, self._models.pop(key))
+        desc = tables.to_c()
+        h = ctypes.c_void_p()
+        self._check(self._lib.mwrt_model_create(self._handle, ctypes.byref(desc), ctypes.byref(h)), "mwrt_model_create")
+        self._models[key] = h
+        self._model_tables[key] = tables
+        return h
+
+    # -- host-buffer entry points ------------------------------------------------------------
+    def tb_batch(self, model, z, p, t, rh, frq, elev, extras=False):
+        """[nprof][nlev] profiles (ground->top) -> tb [nprof][nang][nf], valid [nprof] (+ extras dict)."""
+        z = _f64(z)
+        if z.ndim != 2:
+            raise ValueError("profiles must be [nprof][nlev]")
+        nprof, nlev = z.shape
+        p, t, rh = _f64(p, z.shape, "p"), _f64(t, z.shape, "t"), _f64(rh, z.shape, "rh")
+        frq, elev = _f64(frq).ravel(), _f64(elev).ravel()
+        nf, nang = frq.size, elev.size
+        tb = np.empty((nprof, nang, nf))
+        valid = np.empty(nprof, dtype=np.uint8)
+        ex, exs = None, None
+        if extras:
+            ex = {k: np.empty((nprof, nang, nf)) for k in ("tbatm", "tmr", "tauwet", "taudry")}
+            ex["taulay"] = np.empty((nprof, nf, nlev))
+            exs = MwrtTbExtras(*[ex[k].ctypes.data for k in ("tbatm", "tmr", "tauwet", "taudry", "taulay")])
+        self._check(self._lib.mwrt_tb_batch(
+            self._handle, self.model(model), nprof, nlev, _ptr(z), _ptr(p), _ptr(t), _ptr(rh),
+            nf, _ptr(frq), nang, _ptr(elev), _ptr(tb), _ptr(valid),
+            ctypes.byref(exs) if exs is not None else None), "mwrt_tb_batch")
+        return (tb, valid, ex) if extras else (tb, valid)
+
+    def absorption_batch(self, model, p, t, rh, frq):
+        """-> awet, adry [nprof][nf][nlev] in Np/km."""
+        p = _f64(p)
+        nprof, nlev = p.shape
+        t, rh = _f64(t, p.shape, "t"), _f64(rh, p.shape, "rh")
+        frq = _f64(frq).ravel()
+        awet = np.empty((nprof, frq.size, nlev))
+        adry = np.empty_like(awet)
+        self._check(self._lib.mwrt_absorption_batch(
+            self._handle, self.model(model), nprof, nlev, _ptr(p), _ptr(t), _ptr(rh),
+            frq.size, _ptr(frq), _ptr(awet), _ptr(adry)), "mwrt_absorption_batch")
+        return awet, adry
+
+    # -- device-buffer entry points (raw device addresses, e.g. torch.Tensor.data_ptr()) -------
+    def tb_batch_device(self, model, nprof, nlev, d_z, d_p, d_t, d_rh, frq, elev, d_tb, d_valid,
+                        extras: Optional[MwrtTbExtras] = None, stream: int = 0):
+        frq, elev = _f64(frq).ravel(), _f64(elev).ravel()
+        self._check(self._lib.mwrt_tb_batch_device(
+            self._handle, self.model(model), int(nprof), int(nlev), _ptr(d_z), _ptr(d_p), _ptr(d_t), _ptr(d_rh),
+            frq.size, _ptr(frq), elev.size, _ptr(elev), _ptr(d_tb), _ptr(d_valid),
+            ctypes.byref(extras) if extras is not None else None,
+            ctypes.c_void_p(stream) if stream else None), "mwrt_tb_batch_device")
+
+    def absorption_batch_device(self, model, nprof, nlev, d_p, d_t, d_rh, frq, d_awet, d_adry, stream: int = 0):
+        frq = _f64(frq).ravel()
+        self._check(self._lib.mwrt_absorption_batch_device(
+            self._handle, self.model(model), int(nprof), int(nlev), _ptr(d_p), _ptr(d_t), _ptr(d_rh),
+            frq.size, _ptr(frq), _ptr(d_awet), _ptr(d_adry),
+            ctypes.c_void_p(stream) if stream else None), "mwrt_absorption_batch_device")
+
+    def synchronize(self, stream: int = 0):
+        self._check(self._lib.mwrt_synchronize(self._handle, ctypes.c_void_p(stream) if stream else None),
+                    "mwrt_synchronize")
+
+    def set_timing(self, enabled: bool):
+        self._check(self._lib.mwrt_set_timing(self._handle, int(bool(enabled))), "mwrt_set_timing")
+
+    def last_kernel_ms(self) -> float:
+        ms = ctypes.c_double()
+        self._check(self._lib.mwrt_last_kernel_ms(self._handle, ctypes.byref(ms)), "mwrt_last_kernel_ms")
+        return ms.value
+
+
+_default_ctx: Dict[int, Context] = {}
+
+
+def default_context(device_id: int = 0) -> Context:
+    """Process-wide context per device (what the TbCloudRTE shim uses)."""
+    ctx = _default_ctx.get(device_id)
+    if ctx is None or ctx._handle is None:
+        ctx = _default_ctx[device_id] = Context(device_id)
+    return ctx

@@ -1,0 +1,411 @@
+// mwrt.hip -- C-ABI host side of libmwrt.so (declarations + reference citations: include/mwrt.h).
+//
+// HIP only: there is no CPU fallback in this library.  Without a GPU mwrt_device_count()
+// returns 0 and mwrt_create() fails with MWRT_ERR_NO_DEVICE.
+#include "mwrt_kernels.hip.h"
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+#include <new>
+
+using namespace mwrt;
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const std::string& msg) { g_err = msg; return code; }
+
+#define HIP_TRY(expr)                                                                        \
+  do {                                                                                       \
+    hipError_t e_ = (expr);                                                                  \
+    if (e_ != hipSuccess)                                                                    \
+      return fail(e_ == hipErrorOutOfMemory ? MWRT_ERR_OUT_OF_MEMORY : MWRT_ERR_HIP,         \
+                  std::string(#expr) + ": " + hipGetErrorString(e_));                        \
+  } while (0)
+
+struct DevBuf {
+  void* p = nullptr;
+  size_t cap = 0;
+  hipError_t reserve(size_t bytes) {
+    if (bytes <= cap) return hipSuccess;
+    if (p) { hipError_t e = hipFree(p); p = nullptr; cap = 0; if (e != hipSuccess) return e; }
+    size_t want = bytes + bytes / 8 + 256;
+    hipError_t e = hipMalloc(&p, want);
+    if (e == hipSuccess) cap = want;
+    return e;
+  }
+  void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+  template <class T> T* as() { return static_cast<T*>(p); }
+};
+
+}  // namespace
+
+struct mwrt_context {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  int lds_max = 65536;
+  // small per-call parameter arrays (frq, airmass) cached on the device by content
+  DevBuf d_frq, d_am;
+  std::vector<double> h_frq, h_am;
+  // staging for the host-buffer entry points
+  DevBuf d_in, d_out, d_valid, d_ex;
+  // timing
+  bool timing = false;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  bool ev_pending = false;
+};
+
+struct mwrt_model {
+  mwrt_model_desc* d_desc = nullptr;
+  mwrt_model_desc h_desc;
+};
+
+namespace {
+
+// K2 work split: items = pairs x nseg over `threads` lanes; cost ~ rounds x seglen (+ combine)
+LaunchGeom plan_k2(int nlev, int npairs, int threads) {
+  LaunchGeom g;
+  const int layers = nlev - 1;
+  int best = 1; long best_cost = -1;
+  for (int ns = 1; ns <= 64 && ns <= (layers > 0 ? layers : 1); ++ns) {
+    const int sl = (layers + ns - 1) / ns;
+    const long rounds = ((long)npairs * ns + threads - 1) / threads;
+    const long cost = rounds * (sl * 8L + 4) + ns;      // 8 ~ relative cost of a layer step vs a combine step
+    if (best_cost < 0 || cost < best_cost) { best_cost = cost; best = ns; }
+  }
+  g.nseg = best;
+  g.seglen = (layers + best - 1) / best;
+  if (g.seglen < 1) g.seglen = 1;
+  // row stride in doubles: odd multiple of 2 dwords keeps ds_read_b64 rows on distinct banks
+  int ld = nlev + 1;
+  if ((ld & 1) == 0) ld += 1;
+  g.ldrow = ld;
+  return g;
+}
+
+template <int NFC>
+size_t fused_lds_bytes(const LaunchGeom& g, int nang, int threads) {
+  return sizeof(double) * ((size_t)2 * NFC * g.ldrow + (size_t)3 * NFC * nang * g.nseg + threads / WAVE + 2);
+}
+
+int upload_small(mwrt_context* c, DevBuf& buf, std::vector<double>& cache, const double* src, int n,
+                 hipStream_t st) {
+  if ((int)cache.size() == n && std::memcmp(cache.data(), src, sizeof(double) * n) == 0 && buf.p) return MWRT_OK;
+  // the previous contents may still be read by queued kernels: drain before overwriting
+  HIP_TRY(hipStreamSynchronize(st));
+  if (c->stream != st) HIP_TRY(hipStreamSynchronize(c->stream));
+  HIP_TRY(buf.reserve(sizeof(double) * (size_t)n));
+  cache.assign(src, src + n);
+  HIP_TRY(hipMemcpy(buf.p, cache.data(), sizeof(double) * n, hipMemcpyHostToDevice));
+  return MWRT_OK;
+}
+
+int check_common(const mwrt_context* c, const mwrt_model* m, int64_t nprof, int32_t nlev, int32_t nf) {
+  if (!c || !m) return fail(MWRT_ERR_INVALID_ARGUMENT, "null context or model");
+  if (nprof < 0 || nf < 1) return fail(MWRT_ERR_INVALID_ARGUMENT, "nprof < 0 or nf < 1");
+  if (nlev < 2) return fail(MWRT_ERR_INVALID_ARGUMENT, "nlev < 2");
+  if (nlev > MWRT_MAX_LEVELS) return fail(MWRT_ERR_UNSUPPORTED, "nlev > MWRT_MAX_LEVELS (one lane per level)");
+  if (nprof > 2147483647LL) return fail(MWRT_ERR_UNSUPPORTED, "nprof exceeds grid limit");
+  return MWRT_OK;
+}
+
+bool any_nan(const double* x, int n) {
+  for (int i = 0; i < n; ++i) if (std::isnan(x[i])) return true;
+  return false;
+}
+
+void timing_begin(mwrt_context* c, hipStream_t st) {
+  if (c->timing) { (void)hipEventRecord(c->ev0, st); }
+}
+void timing_end(mwrt_context* c, hipStream_t st) {
+  if (c->timing) { (void)hipEventRecord(c->ev1, st); c->ev_pending = true; }
+}
+
+template <int NFC>
+int launch_fused(mwrt_context* c, FusedArgs a, int64_t nprof, hipStream_t st) {
+  const int threads = ((a.nlev + WAVE - 1) / WAVE) * WAVE;
+  const int nchunks = (a.nf + NFC - 1) / NFC;
+  const int npairs = std::min(NFC, a.nf) * a.nang;
+  a.g = plan_k2(a.nlev, npairs, threads);
+  size_t lds = fused_lds_bytes<NFC>(a.g, a.nang, threads);
+  while (lds > (size_t)c->lds_max && a.g.nseg > 1) {     // shrink the partials if LDS is short
+    a.g.nseg = (a.g.nseg + 1) / 2;
+    a.g.seglen = (a.nlev - 1 + a.g.nseg - 1) / a.g.nseg;
+    lds = fused_lds_bytes<NFC>(a.g, a.nang, threads);
+  }
+  if (lds > (size_t)c->lds_max) return fail(MWRT_ERR_UNSUPPORTED, "LDS budget exceeded (nlev x nang too large)");
+  dim3 grid((unsigned)nprof, (unsigned)nchunks), block(threads);
+  timing_begin(c, st);
+  if (threads <= 256) {
+    auto k = k_tb_fused<NFC, 256>;
+    HIP_TRY(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(k, grid, block, lds, st, a);
+  } else {
+    auto k = k_tb_fused<NFC, 1024>;
+    HIP_TRY(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(k, grid, block, lds, st, a);
+  }
+  timing_end(c, st);
+  HIP_TRY(hipGetLastError());
+  return MWRT_OK;
+}
+
+template <int NFC>
+int launch_absorb(mwrt_context* c, AbsorbArgs a, int64_t nprof, hipStream_t st) {
+  const int threads = ((a.nlev + WAVE - 1) / WAVE) * WAVE;
+  const int nchunks = (a.nf + NFC - 1) / NFC;
+  dim3 grid((unsigned)nprof, (unsigned)nchunks), block(threads);
+  timing_begin(c, st);
+  if (threads <= 256) hipLaunchKernelGGL((k_absorb<NFC, 256>), grid, block, 0, st, a);
+  else hipLaunchKernelGGL((k_absorb<NFC, 1024>), grid, block, 0, st, a);
+  timing_end(c, st);
+  HIP_TRY(hipGetLastError());
+  return MWRT_OK;
+}
+
+// frequency-chunk width: 14 HATPRO channels fit one chunk exactly; other counts use 16 / 8
+int pick_nfc(int nf) {
+  if (nf % 14 == 0 || nf <= 14) return (nf <= 8) ? 8 : 14;
+  return 16;
+}
+
+}  // namespace
+
+extern "C" {
+
+int mwrt_version(void) { return MWRT_VERSION; }
+
+size_t mwrt_model_desc_size(void) { return sizeof(mwrt_model_desc); }
+
+int mwrt_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) { (void)hipGetLastError(); return 0; }
+  return n;
+}
+
+const char* mwrt_last_error(void) { return g_err.c_str(); }
+
+int mwrt_create(int device_id, mwrt_context** out) {
+  if (!out) return fail(MWRT_ERR_INVALID_ARGUMENT, "out is null");
+  *out = nullptr;
+  const int n = mwrt_device_count();
+  if (n <= 0) return fail(MWRT_ERR_NO_DEVICE, "no HIP device: this library has no CPU path");
+  if (device_id < 0 || device_id >= n) return fail(MWRT_ERR_INVALID_ARGUMENT, "device_id out of range");
+  HIP_TRY(hipSetDevice(device_id));
+  mwrt_context* c = new (std::nothrow) mwrt_context();
+  if (!c) return fail(MWRT_ERR_OUT_OF_MEMORY, "host allocation failed");
+  c->device = device_id;
+  hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+  if (e != hipSuccess) { delete c; return fail(MWRT_ERR_HIP, hipGetErrorString(e)); }
+  int lds = 0;
+  if (hipDeviceGetAttribute(&lds, hipDeviceAttributeMaxSharedMemoryPerBlock, device_id) == hipSuccess && lds > 0)
+    c->lds_max = lds;
+  (void)hipEventCreate(&c->ev0);
+  (void)hipEventCreate(&c->ev1);
+  *out = c;
+  return MWRT_OK;
+}
+
+int mwrt_destroy(mwrt_context* c) {
+  if (!c) return MWRT_OK;
+  (void)hipSetDevice(c->device);
+  (void)hipStreamSynchronize(c->stream);
+  c->d_frq.release(); c->d_am.release(); c->d_in.release(); c->d_out.release();
+  c->d_valid.release(); c->d_ex.release();
+  if (c->ev0) (void)hipEventDestroy(c->ev0);
+  if (c->ev1) (void)hipEventDestroy(c->ev1);
+  (void)hipStreamDestroy(c->stream);
+  delete c;
+  return MWRT_OK;
+}
+
+int mwrt_model_create(mwrt_context* c, const mwrt_model_desc* desc, mwrt_model** out) {
+  if (!c || !desc || !out) return fail(MWRT_ERR_INVALID_ARGUMENT, "null argument");
+  *out = nullptr;
+  if (desc->n_h2o < 0 || desc->n_h2o > MWRT_MAX_H2O_LINES || desc->n_o2 < 0 || desc->n_o2 > MWRT_MAX_O2_LINES)
+    return fail(MWRT_ERR_INVALID_ARGUMENT, "line counts out of range");
+  HIP_TRY(hipSetDevice(c->device));
+  mwrt_model* m = new (std::nothrow) mwrt_model();
+  if (!m) return fail(MWRT_ERR_OUT_OF_MEMORY, "host allocation failed");
+  m->h_desc = *desc;
+  hipError_t e = hipMalloc((void**)&m->d_desc, sizeof(mwrt_model_desc));
+  if (e == hipSuccess) e = hipMemcpy(m->d_desc, desc, sizeof(mwrt_model_desc), hipMemcpyHostToDevice);
+  if (e != hipSuccess) { if (m->d_desc) (void)hipFree(m->d_desc); delete m; return fail(MWRT_ERR_HIP, hipGetErrorString(e)); }
+  *out = m;
+  return MWRT_OK;
+}
+
+int mwrt_model_destroy(mwrt_context* c, mwrt_model* m) {
+  if (!m) return MWRT_OK;
+  if (c) { (void)hipSetDevice(c->device); (void)hipStreamSynchronize(c->stream); }
+  if (m->d_desc) (void)hipFree(m->d_desc);
+  delete m;
+  return MWRT_OK;
+}
+
+int mwrt_tb_batch_device(mwrt_context* c, const mwrt_model* m, int64_t nprof, int32_t nlev,
+                         const double* d_z, const double* d_p, const double* d_t, const double* d_rh,
+                         int32_t nf, const double* frq, int32_t nang, const double* elev,
+                         double* d_tb, uint8_t* d_valid, const mwrt_tb_extras* ex, void* stream) {
+  int rc = check_common(c, m, nprof, nlev, nf);
+  if (rc) return rc;
+  if (nang < 1 || nang > MWRT_MAX_ANGLES) return fail(MWRT_ERR_INVALID_ARGUMENT, "nang out of range");
+  if (!d_z || !d_p || !d_t || !d_rh || !frq || !elev || !d_tb || !d_valid)
+    return fail(MWRT_ERR_INVALID_ARGUMENT, "null buffer");
+  HIP_TRY(hipSetDevice(c->device));
+  hipStream_t st = stream ? (hipStream_t)stream : c->stream;
+  if (nprof == 0) return MWRT_OK;
+  const size_t nout = (size_t)nprof * nang * nf;
+  if (any_nan(frq, nf) || any_nan(elev, nang)) {
+    // check_for_nans covers frqs and ang too (PyRTlib_processing.py:77-78): everything stays NaN
+    HIP_TRY(hipMemsetAsync(d_tb, 0xFF, nout * sizeof(double), st));
+    HIP_TRY(hipMemsetAsync(d_valid, 0, (size_t)nprof, st));
+    if (ex) {
+      if (ex->tbatm) HIP_TRY(hipMemsetAsync(ex->tbatm, 0xFF, nout * sizeof(double), st));
+      if (ex->tmr) HIP_TRY(hipMemsetAsync(ex->tmr, 0xFF, nout * sizeof(double), st));
+      if (ex->tauwet) HIP_TRY(hipMemsetAsync(ex->tauwet, 0xFF, nout * sizeof(double), st));
+      if (ex->taudry) HIP_TRY(hipMemsetAsync(ex->taudry, 0xFF, nout * sizeof(double), st));
+      if (ex->taulay) HIP_TRY(hipMemsetAsync(ex->taulay, 0xFF, (size_t)nprof * nf * nlev * sizeof(double), st));
+    }
+    return MWRT_OK;
+  }
+  std::vector<double> am(nang);
+  for (int a = 0; a < nang; ++a) am[a] = 1.0 / std::sin(elev[a] * M_PI / 180.0);   // plane-parallel air mass
+  rc = upload_small(c, c->d_frq, c->h_frq, frq, nf, st); if (rc) return rc;
+  rc = upload_small(c, c->d_am, c->h_am, am.data(), nang, st); if (rc) return rc;
+  HIP_TRY(hipMemsetAsync(d_valid, 1, (size_t)nprof, st));
+
+  FusedArgs a{};
+  a.M = m->d_desc; a.z = d_z; a.p = d_p; a.t = d_t; a.rh = d_rh;
+  a.frq = c->d_frq.as<double>(); a.airmass = c->d_am.as<double>();
+  a.tb = d_tb; a.valid = d_valid;
+  if (ex) { a.tbatm = ex->tbatm; a.tmr = ex->tmr; a.tauwet = ex->tauwet; a.taudry = ex->taudry; a.taulay = ex->taulay; }
+  a.nlev = nlev; a.nf = nf; a.nang = nang;
+  switch (pick_nfc(nf)) {
+    case 8: return launch_fused<8>(c, a, nprof, st);
+    case 14: return launch_fused<14>(c, a, nprof, st);
+    default: return launch_fused<16>(c, a, nprof, st);
+  }
+}
+
+int mwrt_tb_batch(mwrt_context* c, const mwrt_model* m, int64_t nprof, int32_t nlev,
+                  const double* z, const double* p, const double* t, const double* rh,
+                  int32_t nf, const double* frq, int32_t nang, const double* elev,
+                  double* tb, uint8_t* valid, const mwrt_tb_extras* ex) {
+  int rc = check_common(c, m, nprof, nlev, nf);
+  if (rc) return rc;
+  if (nang < 1 || nang > MWRT_MAX_ANGLES) return fail(MWRT_ERR_INVALID_ARGUMENT, "nang out of range");
+  if (!z || !p || !t || !rh || !frq || !elev || !tb || !valid) return fail(MWRT_ERR_INVALID_ARGUMENT, "null buffer");
+  if (nprof == 0) return MWRT_OK;
+  HIP_TRY(hipSetDevice(c->device));
+  hipStream_t st = c->stream;
+  const size_t nin = (size_t)nprof * nlev, nout = (size_t)nprof * nang * nf;
+  const size_t nlay = (size_t)nprof * nf * nlev;
+  HIP_TRY(c->d_in.reserve(4 * nin * sizeof(double)));
+  HIP_TRY(c->d_out.reserve(nout * sizeof(double)));
+  HIP_TRY(c->d_valid.reserve((size_t)nprof));
+  double* din = c->d_in.as<double>();
+  const double* src[4] = {z, p, t, rh};
+  for (int k = 0; k < 4; ++k)
+    HIP_TRY(hipMemcpyAsync(din + k * nin, src[k], nin * sizeof(double), hipMemcpyHostToDevice, st));
+  mwrt_tb_extras dex{};
+  double* host_ex[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+  if (ex) {
+    host_ex[0] = ex->tbatm; host_ex[1] = ex->tmr; host_ex[2] = ex->tauwet; host_ex[3] = ex->taudry; host_ex[4] = ex->taulay;
+    size_t need = 0;
+    for (int k = 0; k < 4; ++k) if (host_ex[k]) need += nout;
+    if (host_ex[4]) need += nlay;
+    HIP_TRY(c->d_ex.reserve(need * sizeof(double) + 8));
+    double* q = c->d_ex.as<double>();
+    double** slots[5] = {&dex.tbatm, &dex.tmr, &dex.tauwet, &dex.taudry, &dex.taulay};
+    for (int k = 0; k < 5; ++k) if (host_ex[k]) { *slots[k] = q; q += (k < 4 ? nout : nlay); }
+  }
+  rc = mwrt_tb_batch_device(c, m, nprof, nlev, din, din + nin, din + 2 * nin, din + 3 * nin, nf, frq, nang, elev,
+                            c->d_out.as<double>(), c->d_valid.as<uint8_t>(), ex ? &dex : nullptr, st);
+  if (rc) return rc;
+  HIP_TRY(hipMemcpyAsync(tb, c->d_out.p, nout * sizeof(double), hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipMemcpyAsync(valid, c->d_valid.p, (size_t)nprof, hipMemcpyDeviceToHost, st));
+  if (ex) {
+    double* dptr[5] = {dex.tbatm, dex.tmr, dex.tauwet, dex.taudry, dex.taulay};
+    for (int k = 0; k < 5; ++k)
+      if (host_ex[k]) HIP_TRY(hipMemcpyAsync(host_ex[k], dptr[k], (k < 4 ? nout : nlay) * sizeof(double), hipMemcpyDeviceToHost, st));
+  }
+  HIP_TRY(hipStreamSynchronize(st));
+  return MWRT_OK;
+}
+
+int mwrt_absorption_batch_device(mwrt_context* c, const mwrt_model* m, int64_t nprof, int32_t nlev,
+                                 const double* d_p, const double* d_t, const double* d_rh,
+                                 int32_t nf, const double* frq, double* d_awet, double* d_adry, void* stream) {
+  int rc = check_common(c, m, nprof, nlev, nf);
+  if (rc) return rc;
+  if (!d_p || !d_t || !d_rh || !frq || !d_awet || !d_adry) return fail(MWRT_ERR_INVALID_ARGUMENT, "null buffer");
+  if (any_nan(frq, nf)) return fail(MWRT_ERR_INVALID_ARGUMENT, "NaN frequency");
+  HIP_TRY(hipSetDevice(c->device));
+  hipStream_t st = stream ? (hipStream_t)stream : c->stream;
+  if (nprof == 0) return MWRT_OK;
+  rc = upload_small(c, c->d_frq, c->h_frq, frq, nf, st); if (rc) return rc;
+  AbsorbArgs a{};
+  a.M = m->d_desc; a.p = d_p; a.t = d_t; a.rh = d_rh; a.frq = c->d_frq.as<double>();
+  a.awet = d_awet; a.adry = d_adry; a.nlev = nlev; a.nf = nf;
+  switch (pick_nfc(nf)) {
+    case 8: return launch_absorb<8>(c, a, nprof, st);
+    case 14: return launch_absorb<14>(c, a, nprof, st);
+    default: return launch_absorb<16>(c, a, nprof, st);
+  }
+}
+
+int mwrt_absorption_batch(mwrt_context* c, const mwrt_model* m, int64_t nprof, int32_t nlev,
+                          const double* p, const double* t, const double* rh,
+                          int32_t nf, const double* frq, double* awet, double* adry) {
+  int rc = check_common(c, m, nprof, nlev, nf);
+  if (rc) return rc;
+  if (!p || !t || !rh || !frq || !awet || !adry) return fail(MWRT_ERR_INVALID_ARGUMENT, "null buffer");
+  if (nprof == 0) return MWRT_OK;
+  HIP_TRY(hipSetDevice(c->device));
+  hipStream_t st = c->stream;
+  const size_t nin = (size_t)nprof * nlev, nout = (size_t)nprof * nf * nlev;
+  HIP_TRY(c->d_in.reserve(3 * nin * sizeof(double)));
+  HIP_TRY(c->d_out.reserve(2 * nout * sizeof(double)));
+  double* din = c->d_in.as<double>();
+  const double* src[3] = {p, t, rh};
+  for (int k = 0; k < 3; ++k)
+    HIP_TRY(hipMemcpyAsync(din + k * nin, src[k], nin * sizeof(double), hipMemcpyHostToDevice, st));
+  double* dout = c->d_out.as<double>();
+  rc = mwrt_absorption_batch_device(c, m, nprof, nlev, din, din + nin, din + 2 * nin, nf, frq, dout, dout + nout, st);
+  if (rc) return rc;
+  HIP_TRY(hipMemcpyAsync(awet, dout, nout * sizeof(double), hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipMemcpyAsync(adry, dout + nout, nout * sizeof(double), hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipStreamSynchronize(st));
+  return MWRT_OK;
+}
+
+int mwrt_synchronize(mwrt_context* c, void* stream) {
+  if (!c) return fail(MWRT_ERR_INVALID_ARGUMENT, "null context");
+  HIP_TRY(hipSetDevice(c->device));
+  HIP_TRY(hipStreamSynchronize(stream ? (hipStream_t)stream : c->stream));
+  return MWRT_OK;
+}
+
+int mwrt_set_timing(mwrt_context* c, int enabled) {
+  if (!c) return fail(MWRT_ERR_INVALID_ARGUMENT, "null context");
+  c->timing = enabled != 0;
+  c->ev_pending = false;
+  return MWRT_OK;
+}
+
+int mwrt_last_kernel_ms(mwrt_context* c, double* ms_out) {
+  if (!c || !ms_out) return fail(MWRT_ERR_INVALID_ARGUMENT, "null argument");
+  if (!c->ev_pending) return fail(MWRT_ERR_INVALID_ARGUMENT, "no timed launch pending");
+  HIP_TRY(hipEventSynchronize(c->ev1));
+  float ms = 0.f;
+  HIP_TRY(hipEventElapsedTime(&ms, c->ev0, c->ev1));
+  *ms_out = ms;
+  return MWRT_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,526 @@
+// mwrt_kernels.hip.h -- hand-written gfx950 (CDNA4) kernels of the LBL forward operator.
+//
+// Mapping: one workgroup = one (profile, frequency-chunk); one LANE = one LEVEL
+// of that profile.  Line tables and frequencies are wave-uniform, so they travel through the
+// scalar unit (s_load) and every per-(level,line) transcendental is evaluated once per lane and
+// reused for the NFC frequencies of the chunk.  Phase K1 leaves zenith layer optical depths and
+// Planck functions in LDS; phase K2 integrates the slant-path RTE out of LDS for all
+// (frequency, angle) pairs; nothing but the 4 profile fields and the TBs touches HBM.
+//
+// Arithmetic restates pyrtlib [EXT] (not in /root/reference): RTEquation.vapor,
+// clearsky_absorption -> H2OAbsModel.h2o_absorption / O2AbsModel.o2_absorption /
+// N2AbsModel.n2_absorption, exponential_integration, planck, bright -- the routines that
+// TbCloudRTE.execute() runs when called from reference python_src/proc/PyRTlib_processing.py:126.
+// fp64 throughout ("dtype": "f64"); no MFMA: this is elementwise + scan work.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/mwrt.h"
+
+namespace mwrt {
+
+constexpr int WAVE = 64;
+constexpr double TAUMAX = 125.0;
+
+struct LaunchGeom {          // host-computed K2 work split (see plan_k2 in mwrt.hip)
+  int nseg;                  // level segments per (freq, angle) pair
+  int seglen;                // layers per segment
+  int ldrow;                 // padded LDS row length (doubles) of tau/boft: conflict-free for b64
+};
+
+// ---------------------------------------------------------------------------------------------
+// small helpers
+// ---------------------------------------------------------------------------------------------
+#ifndef MWRT_EXACT_DIV
+#define MWRT_EXACT_DIV 0
+#endif
+
+// x / d with v_rcp_f64 + two Newton steps (error ~1 ulp; parity bar is 1e-6 K, budget 0.01 K).
+__device__ __forceinline__ double fdiv(double x, double d) {
+#if MWRT_EXACT_DIV
+  return x / d;
+#else
+  double r = __builtin_amdgcn_rcp(d);
+  double e = __builtin_fma(-d, r, 1.0);
+  r = __builtin_fma(r, e, r);
+  e = __builtin_fma(-d, r, 1.0);
+  r = __builtin_fma(r, e, r);
+  double q = x * r;
+  // one residual correction makes q correctly rounded in all but pathological cases
+  return __builtin_fma(__builtin_fma(-d, q, x), r, q);
+#endif
+}
+
+struct cplx { double re, im; };
+__device__ __forceinline__ cplx cmul(cplx a, cplx b) { return {a.re * b.re - a.im * b.im, a.re * b.im + a.im * b.re}; }
+__device__ __forceinline__ cplx cadd(cplx a, double r) { return {a.re + r, a.im}; }
+__device__ __forceinline__ cplx cdiv(cplx a, cplx b) {
+  double d = b.re * b.re + b.im * b.im;
+  return {fdiv(a.re * b.re + a.im * b.im, d), fdiv(a.im * b.re - a.re * b.im, d)};
+}
+__device__ __forceinline__ cplx csqrt_principal(cplx z) {
+  double r = sqrt(z.re * z.re + z.im * z.im);
+  if (z.re >= 0.0) {
+    double a = sqrt(0.5 * (r + z.re));
+    return {a, (a > 0.0) ? fdiv(z.im, 2.0 * a) : 0.0};
+  }
+  double b = sqrt(0.5 * (r - z.re));
+  return {fdiv(fabs(z.im), 2.0 * b), copysign(b, z.im)};
+}
+
+// Rosenkranz DCERROR [EXT]: Hui, Armstrong & Wray (1978) rational approximation of the complex
+// error function, upper half plane (y >= 0 always holds here: y = Re(principal sqrt)).
+__device__ __forceinline__ cplx dcerror_upper(double x, double y) {
+  const double a0 = 122.607931777104326, a1 = 214.382388694706425, a2 = 181.928533092181549,
+               a3 = 93.155580458138441, a4 = 30.180142196210589, a5 = 5.912626209773153,
+               a6 = 0.564189583562615;
+  const double b0 = 122.607931773875350, b1 = 352.730625110963558, b2 = 457.334478783897737,
+               b3 = 348.703917719495792, b4 = 170.354001821091472, b5 = 53.992906912940207,
+               b6 = 10.479857114260399;
+  cplx zh = {fabs(y), -x};
+  cplx as = {a6 * zh.re + a5, a6 * zh.im};
+  as = cadd(cmul(as, zh), a4); as = cadd(cmul(as, zh), a3); as = cadd(cmul(as, zh), a2);
+  as = cadd(cmul(as, zh), a1); as = cadd(cmul(as, zh), a0);
+  cplx bs = {zh.re + b6, zh.im};
+  bs = cadd(cmul(bs, zh), b5); bs = cadd(cmul(bs, zh), b4); bs = cadd(cmul(bs, zh), b3);
+  bs = cadd(cmul(bs, zh), b2); bs = cadd(cmul(bs, zh), b1); bs = cadd(cmul(bs, zh), b0);
+  return cdiv(as, bs);
+}
+
+// deterministic workgroup sum (fixed order: lanes by butterfly, then waves in index order)
+__device__ __forceinline__ double block_sum(double v, double* scratch /*[nwaves]*/, int tid, int nthreads) {
+#pragma unroll
+  for (int o = WAVE / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, WAVE);
+  __syncthreads();
+  if ((tid & (WAVE - 1)) == 0) scratch[tid / WAVE] = v;
+  __syncthreads();
+  double s = 0.0;
+  for (int w = 0; w < nthreads / WAVE; ++w) s += scratch[w];
+  return s;
+}
+
+// ---------------------------------------------------------------------------------------------
+// per-level state shared by the H2O / O2 / N2 evaluations (RTEquation.vapor +
+// clearsky_absorption preamble [EXT], incl. pyrtlib's kPa round trip)
+// ---------------------------------------------------------------------------------------------
+struct LevelState {
+  double t;       // K    (300/(300/tk))
+  double p;       // hPa  ((pdrykpa+ekpa)*10)
+  double rho;     // g m-3
+  double pdry;    // hPa  (pdrykpa*10)
+};
+
+__device__ __forceinline__ double goff_gratch_e(double tk, double rh) {
+  const double LN10 = 2.302585092994045684;
+  const double INV_LN10 = 0.434294481903251828;
+  double y = 373.16 / tk;
+  double es = -7.90298 * (y - 1.0) + 5.02808 * (log(y) * INV_LN10)
+            - 1.3816e-07 * (exp(LN10 * (11.344 * (1.0 - (1.0 / y)))) - 1.0)
+            + 0.0081328 * (exp(LN10 * (-3.49149 * (y - 1.0))) - 1.0) + 3.0057148979490314 /*log10(1013.246)*/;
+  return rh * exp(LN10 * es);
+}
+
+__device__ __forceinline__ LevelState level_state(double p_hpa, double tk, double e) {
+  const double rvap = (0.01 * 8.314510) / 18.01528;
+  double v = 300.0 / tk;
+  double ekpa = e / 10.0;
+  double pdrykpa = p_hpa / 10.0 - ekpa;
+  LevelState s;
+  s.t = 300.0 / v;
+  s.p = (pdrykpa + ekpa) * 10.0;
+  s.rho = ekpa * 10.0 / (rvap * s.t);
+  s.pdry = pdrykpa * 10.0;
+  return s;
+}
+
+// ---------------------------------------------------------------------------------------------
+// K1a: H2O lines + continuum for NFC uniform frequencies (H2OAbsModel.h2o_absorption [EXT])
+// ---------------------------------------------------------------------------------------------
+template <int NFC>
+__device__ __forceinline__ void h2o_absorb(const mwrt_model_desc* __restrict__ M, const LevelState& L,
+                                           const double* __restrict__ fq /*uniform, NFC valid*/,
+                                           double (&awet)[NFC]) {
+  const double t = L.t;
+  const double pvap = fdiv(L.rho * t, M->h2o_pvap_div);
+  const double pda = L.p - pvap;
+  const double den = M->h2o_den_coef * L.rho;
+  const double lnc = log(fdiv(M->h2o_reftcon, t));
+  const double con0 = (M->h2o_cf * pda * exp(M->h2o_xcf * lnc) + M->h2o_cs * pvap * exp(M->h2o_xcs * lnc)) * pvap;
+  const double ti = fdiv(M->h2o_reftline, t);
+  const double tiln = log(ti);
+  const double ti2 = exp(2.5 * tiln);
+  const bool shifted = M->h2o_shift_mode != 0;
+  double sum[NFC];
+#pragma unroll
+  for (int j = 0; j < NFC; ++j) sum[j] = 0.0;
+
+  const int nl = M->n_h2o;
+  for (int k = 0; k < nl; ++k) {
+    const double fl = M->h2o_fl[k];
+    const double w0 = M->h2o_w0[k] * pda * exp(M->h2o_x[k] * tiln) + M->h2o_w0s[k] * pvap * exp(M->h2o_xs[k] * tiln);
+    double shift = 0.0;
+    if (shifted) {
+      shift = M->h2o_sh[k] * pda * (1.0 - M->h2o_aair[k] * tiln) * exp(M->h2o_xh[k] * tiln)
+            + M->h2o_shs[k] * pvap * (1.0 - M->h2o_aself[k] * tiln) * exp(M->h2o_xhs[k] * tiln);
+    }
+    const double wsq = w0 * w0;
+    // S * (f/fl)^2: the f^2 is applied once at the end
+    const double s = fdiv(M->h2o_s1[k] * ti2 * exp(M->h2o_b2[k] * (1.0 - ti)), fl * fl);
+    const double base = fdiv(w0, 562500.0 + wsq);
+    const double c1 = fl + shift;
+    const bool sd_line = M->h2o_w2[k] > 0.0;      // wave-uniform
+    double w2 = 0.0, delta2 = 0.0;
+    if (sd_line) {
+      w2 = M->h2o_w2[k] * pda * exp(M->h2o_xw2[k] * tiln) + M->h2o_w2s[k] * pvap * exp(M->h2o_xw2s[k] * tiln);
+      delta2 = M->h2o_d2[k] * pda + M->h2o_d2s[k] * pvap;
+    }
+#pragma unroll
+    for (int j = 0; j < NFC; ++j) {
+      const double f = fq[j];
+      const double d1 = f - c1;
+      const double d2 = f + c1;
+      double res = 0.0;
+      double r1 = (fabs(d1) < 750.0) ? (fdiv(w0, d1 * d1 + wsq) - base) : 0.0;
+      if (sd_line && w2 > 0.0 && fabs(d1) < 10.0 * w0) {
+        // speed-dependent resonant shape factor (ABH2O_SD): Xc = (w0-1.5w2 + i(d1+1.5 delta2)) / (w2 - i delta2)
+        cplx den2 = {w2, -delta2};
+        cplx xc = cdiv(cplx{w0 - 1.5 * w2, d1 + 1.5 * delta2}, den2);
+        cplx xrt = csqrt_principal(xc);
+        cplx w = dcerror_upper(-xrt.im, xrt.re);
+        cplx pxw = cmul(cplx{1.77245385090551603 * xrt.re, 1.77245385090551603 * xrt.im}, w);
+        cplx sd = cdiv(cplx{2.0 * (1.0 - pxw.re), -2.0 * pxw.im}, den2);
+        r1 = sd.re - base;
+      }
+      res += r1;
+      if (fabs(d2) < 750.0) res += fdiv(w0, d2 * d2 + wsq) - base;
+      sum[j] = __builtin_fma(s, res, sum[j]);
+    }
+  }
+  const bool dry = !(L.rho > 0.0);
+#pragma unroll
+  for (int j = 0; j < NFC; ++j) {
+    const double f2 = fq[j] * fq[j];
+    awet[j] = dry ? 0.0 : (3.183e-05 * den * sum[j] + con0) * f2;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// K1b: O2 lines + non-resonant + N2 continuum (O2AbsModel.o2_absorption / N2AbsModel [EXT])
+// ---------------------------------------------------------------------------------------------
+template <int NFC>
+__device__ __forceinline__ void dry_absorb(const mwrt_model_desc* __restrict__ M, const LevelState& L,
+                                           const double* __restrict__ fq, double (&adry)[NFC]) {
+  const double temp = L.t;
+  const double pres = L.p;
+  const double th = fdiv(300.0, temp);
+  const double th1 = th - 1.0;
+  const double lnth = log(th);
+  const double b = exp(M->o2_x * lnth);
+  const double preswv = fdiv(L.rho * temp, M->o2_pvap_div);
+  const double presda = pres - preswv;
+  const double den = 0.001 * (presda * b + M->o2_wv_factor * preswv * th);
+  const double dens = 0.001 * (presda + M->o2_wv_factor * preswv) * th;
+  const double dfnr = M->o2_wb300 * den;
+  const double pe2 = den * den;
+  const bool second = M->o2_mix_mode != 0;
+  const double ymul = second ? den : 0.001 * pres * b;
+
+  double sum[NFC];
+#pragma unroll
+  for (int j = 0; j < NFC; ++j) sum[j] = 0.0;
+
+  const int nl = M->n_o2;
+  for (int k = 0; k < nl; ++k) {
+    const double fk = M->o2_f[k];
+    const double y = ymul * (M->o2_y0[k] + M->o2_y1[k] * th1);
+    double dnu = 0.0, gfac = 1.0;
+    if (second) {
+      dnu = pe2 * (M->o2_dnu0[k] + M->o2_dnu1[k] * th1);
+      gfac = 1.0 + pe2 * (M->o2_g0[k] + M->o2_g1[k] * th1);
+    }
+    const double df = M->o2_w300[k] * ((k == 0 && M->o2_line1_dens) ? dens : den);
+    const double str = fdiv(M->o2_s300[k] * exp(-M->o2_be[k] * th1), fk * fk);   // * f^2 at the end
+    const double c1 = fk + dnu;
+    const double df2 = df * df;
+    const double a = str * df * gfac;
+    const double bb = str * y;
+#pragma unroll
+    for (int j = 0; j < NFC; ++j) {
+      const double f = fq[j];
+      const double d1 = f - c1;
+      const double d2 = f + c1;
+      const double D1 = __builtin_fma(d1, d1, df2);
+      const double D2 = __builtin_fma(d2, d2, df2);
+      const double n1 = __builtin_fma(d1, bb, a);
+      const double n2 = __builtin_fma(-d2, bb, a);
+      // n1/D1 + n2/D2 with a single reciprocal
+      sum[j] += fdiv(__builtin_fma(n1, D2, n2 * D1), D1 * D2);
+    }
+  }
+  const double scale = M->o2_coef * presda * th * th * th;
+  // N2 collision-induced continuum (ABSN2): p^2 f^2 th^m
+  const double pn2 = M->n2_ptot ? pres : L.pdry;
+  const double n2c = M->n2_n * M->n2_l * pn2 * pn2 * exp(M->n2_m * lnth);
+#pragma unroll
+  for (int j = 0; j < NFC; ++j) {
+    const double f = fq[j];
+    const double f2 = f * f;
+    const double nonres = fdiv(M->o2_nonres * f2 * dfnr, th * (f2 + dfnr * dfnr));
+    double o2 = scale * __builtin_fma(sum[j], f2, nonres);
+    o2 = fmax(o2, 0.0);
+    double fdep = 1.0;
+    if (M->n2_fdep) { const double q = f * (1.0 / 450.0); fdep = 0.5 + fdiv(0.5, 1.0 + q * q); }
+    adry[j] = o2 + n2c * fdep * f2;
+  }
+}
+
+// RTEquation.exponential_integration [EXT]: log-mean ("exponential decay") layer value.
+// Branch order is the contract.  Returns NaN-flag through `neg`.
+__device__ __forceinline__ double layer_value(double x1, double x0, bool& neg) {
+  if (x0 < 0.0 || x1 < 0.0) { neg = true; return 0.0; }
+  if (fabs(x1 - x0) < 1e-09) return x1;
+  if (x0 == 0.0 || x1 == 0.0) return (x1 + x0) * 0.5;          // zeroflg = True for wet & dry
+  return fdiv(x1 - x0, log(fdiv(x1, x0)));
+}
+
+// ---------------------------------------------------------------------------------------------
+// fused kernel: profile in -> TB out
+// ---------------------------------------------------------------------------------------------
+struct FusedArgs {
+  const mwrt_model_desc* M;
+  const double* z; const double* p; const double* t; const double* rh;   // [nprof][nlev]
+  const double* frq;       // [nf] device
+  const double* airmass;   // [nang] device: 1/sin(elev)
+  double* tb;              // [nprof][nang][nf]
+  uint8_t* valid;          // [nprof]
+  double* tbatm; double* tmr; double* tauwet; double* taudry;   // optional [nprof][nang][nf]
+  double* taulay;          // optional [nprof][nf][nlev]
+  int nlev, nf, nang;
+  LaunchGeom g;
+};
+
+template <int NFC, int MAXT>
+__global__ void __launch_bounds__(MAXT)
+k_tb_fused(const FusedArgs A) {
+  extern __shared__ double lds[];
+  const int tid = threadIdx.x;
+  const int nthreads = blockDim.x;
+  const int64_t prof = blockIdx.x;
+  const int jbase = blockIdx.y * NFC;
+  const int nfc = min(NFC, A.nf - jbase);
+  const int nlev = A.nlev, nang = A.nang, ld = A.g.ldrow;
+  const mwrt_model_desc* __restrict__ M = A.M;
+
+  double* tau = lds;                        // [NFC][ld]  zenith layer optical depth (wet+dry)
+  double* bof = lds + (size_t)NFC * ld;     // [NFC][ld]  Planck function B(T_i, f_j)
+  double* part = bof + (size_t)NFC * ld;    // [items][3] segment partials (B, T, sum tau)
+  double* scratch = part + (size_t)3 * NFC * nang * A.g.nseg;  // [nwaves]
+  __shared__ int s_flag;
+
+  // uniform frequency chunk; lanes beyond nfc reuse the last valid one (results discarded)
+  double fq[NFC];
+#pragma unroll
+  for (int j = 0; j < NFC; ++j) fq[j] = A.frq[jbase + min(j, nfc - 1)];
+
+  if (tid == 0) s_flag = 0;
+  __syncthreads();
+
+  const bool active = tid < nlev;
+  const int64_t off = prof * nlev + (active ? tid : 0);
+  const double zi = A.z[off], pi = A.p[off], ti = A.t[off], rhi = A.rh[off];
+  if (active && (isnan(zi) || isnan(pi) || isnan(ti) || isnan(rhi))) atomicOr(&s_flag, 1);
+  __syncthreads();
+  if (s_flag) {                               // check_for_nans: outputs stay NaN, valid = 0
+    const double qnan = __builtin_nan("");
+    for (int it = tid; it < nfc * nang; it += nthreads) {
+      const int j = it / nang, a = it % nang;
+      const int64_t o = (prof * nang + a) * A.nf + jbase + j;
+      A.tb[o] = qnan;
+      if (A.tbatm) A.tbatm[o] = qnan;
+      if (A.tmr) A.tmr[o] = qnan;
+      if (A.tauwet) A.tauwet[o] = qnan;
+      if (A.taudry) A.taudry[o] = qnan;
+    }
+    if (A.taulay) for (int it = tid; it < nfc * nlev; it += nthreads)
+      A.taulay[(prof * A.nf + jbase + it / nlev) * nlev + it % nlev] = qnan;
+    if (tid == 0) A.valid[prof] = 0;          // valid[] is preset to 1 by the host
+    return;
+  }
+
+  // ---- phase K1: absorption at my level for the NFC frequencies ----
+  double awet[NFC], adry[NFC];
+  {
+    const double e = goff_gratch_e(ti, rhi);
+    const LevelState L = level_state(pi, ti, e);
+    h2o_absorb<NFC>(M, L, fq, awet);
+    dry_absorb<NFC>(M, L, fq, adry);
+  }
+  if (active) {
+#pragma unroll
+    for (int j = 0; j < NFC; ++j) { tau[j * ld + tid] = awet[j]; bof[j * ld + tid] = adry[j]; }
+  }
+  __syncthreads();
+  // layer optical depth (zenith): needs level i-1
+  double tw[NFC], td[NFC];
+  bool neg = false;
+  const double z0 = A.z[prof * nlev];         // execute() works in height above the antenna
+  const double dz = (active && tid > 0) ? ((zi - z0) - (A.z[off - 1] - z0)) : 0.0;
+  if (active && tid > 0) {
+#pragma unroll
+    for (int j = 0; j < NFC; ++j) {
+      tw[j] = layer_value(awet[j], tau[j * ld + tid - 1], neg) * dz;
+      td[j] = layer_value(adry[j], bof[j * ld + tid - 1], neg) * dz;
+    }
+  } else {
+#pragma unroll
+    for (int j = 0; j < NFC; ++j) { tw[j] = 0.0; td[j] = 0.0; }
+  }
+  if (neg) atomicOr(&s_flag, 2);
+  __syncthreads();
+  if (s_flag) {                               // pyrtlib raises ValueError here: flag 2, NaN out
+    const double qnan = __builtin_nan("");
+    for (int it = tid; it < nfc * nang; it += nthreads) {
+      const int j = it / nang, a = it % nang;
+      const int64_t o = (prof * nang + a) * A.nf + jbase + j;
+      A.tb[o] = qnan;
+      if (A.tbatm) A.tbatm[o] = qnan;
+      if (A.tmr) A.tmr[o] = qnan;
+      if (A.tauwet) A.tauwet[o] = qnan;
+      if (A.taudry) A.taudry[o] = qnan;
+    }
+    if (A.taulay) for (int it = tid; it < nfc * nlev; it += nthreads)
+      A.taulay[(prof * A.nf + jbase + it / nlev) * nlev + it % nlev] = qnan;
+    if (tid == 0) A.valid[prof] = 2;
+    return;
+  }
+  const double hk = 1e9 * M->planck_h / M->boltzmann_k;
+  if (active) {
+#pragma unroll
+    for (int j = 0; j < NFC; ++j) {
+      tau[j * ld + tid] = tw[j] + td[j];
+      bof[j * ld + tid] = fdiv(1.0, exp(fdiv(fq[j] * hk, ti)) - 1.0);
+    }
+    if (A.taulay) {
+#pragma unroll
+      for (int j = 0; j < NFC; ++j)
+        if (j < nfc) A.taulay[(prof * A.nf + jbase + j) * nlev + tid] = tw[j] + td[j];
+    }
+  }
+  // optional zenith opacity sums (tauwet / taudry columns)
+  double swet[NFC], sdry[NFC];
+  const bool want_tau = (A.tauwet != nullptr) || (A.taudry != nullptr);
+  if (want_tau) {
+#pragma unroll
+    for (int j = 0; j < NFC; ++j) {
+      swet[j] = block_sum(tw[j], scratch, tid, nthreads);
+      sdry[j] = block_sum(td[j], scratch, tid, nthreads);
+    }
+  }
+  __syncthreads();
+
+  // ---- phase K2: slant-path RTE (RTEquation.planck, from_sat = False [EXT]) ----
+  const int npairs = nfc * nang;
+  const int nseg = A.g.nseg, seglen = A.g.seglen;
+  const int items = npairs * nseg;
+  for (int it = tid; it < items; it += nthreads) {
+    const int seg = it / npairs;
+    const int pr = it - seg * npairs;
+    const int j = pr / nang;
+    const int a = pr - j * nang;
+    const double am = A.airmass[a];
+    const int lo = 1 + seg * seglen;
+    const int hi = min(lo + seglen, nlev);
+    const double* tj = tau + j * ld;
+    const double* bj = bof + j * ld;
+    double T = 1.0, B = 0.0, S = 0.0;
+    double bprev = (lo < nlev) ? bj[lo - 1] : 0.0;
+    for (int i = lo; i < hi; ++i) {
+      const double tl = tj[i] * am;
+      const double E = exp(-tl);
+      const double bi = bj[i];
+      const double lay = fdiv(__builtin_fma(bi, E, bprev), 1.0 + E);
+      B = __builtin_fma(lay * T, 1.0 - E, B);
+      T *= E;
+      S += tl;
+      bprev = bi;
+    }
+    part[3 * it + 0] = B; part[3 * it + 1] = T; part[3 * it + 2] = S;
+  }
+  __syncthreads();
+  for (int pr = tid; pr < npairs; pr += nthreads) {
+    const int j = pr / nang;
+    const int a = pr - j * nang;
+    double B = 0.0, T = 1.0, S = 0.0;
+    for (int s = 0; s < nseg; ++s) {
+      const double* q = part + 3 * (s * npairs + pr);
+      B = __builtin_fma(T, q[0], B);
+      T *= q[1];
+      S += q[2];
+    }
+    const double hvk = A.frq[jbase + j] * hk;
+    double boftotl, boftmr;
+    if (S < TAUMAX) {
+      const double ex = exp(-S);
+      const double bbg = fdiv(1.0, exp(fdiv(hvk, M->t_cosmic)) - 1.0);
+      boftotl = __builtin_fma(bbg, ex, B);
+      boftmr = fdiv(B, 1.0 - ex);
+    } else {
+      boftotl = B; boftmr = B;
+    }
+    const int64_t o = (prof * nang + a) * A.nf + jbase + j;
+    A.tb[o] = fdiv(hvk, log(1.0 + fdiv(1.0, boftotl)));
+    if (A.tbatm) A.tbatm[o] = fdiv(hvk, log(1.0 + fdiv(1.0, B)));
+    if (A.tmr) A.tmr[o] = fdiv(hvk, log(1.0 + fdiv(1.0, boftmr)));
+    if (want_tau) {
+      const double am = A.airmass[a];
+      double sw = 0.0, sd = 0.0;
+#pragma unroll
+      for (int jj = 0; jj < NFC; ++jj) if (jj == j) { sw = swet[jj]; sd = sdry[jj]; }
+      if (A.tauwet) A.tauwet[o] = sw * am;
+      if (A.taudry) A.taudry[o] = sd * am;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// K1 alone: awet / adry [nprof][nf][nlev] (RTEquation.clearsky_absorption [EXT])
+// ---------------------------------------------------------------------------------------------
+struct AbsorbArgs {
+  const mwrt_model_desc* M;
+  const double* p; const double* t; const double* rh;
+  const double* frq;
+  double* awet; double* adry;
+  int nlev, nf;
+};
+
+template <int NFC, int MAXT>
+__global__ void __launch_bounds__(MAXT)
+k_absorb(const AbsorbArgs A) {
+  const int tid = threadIdx.x;
+  const int64_t prof = blockIdx.x;
+  const int jbase = blockIdx.y * NFC;
+  const int nfc = min(NFC, A.nf - jbase);
+  double fq[NFC];
+#pragma unroll
+  for (int j = 0; j < NFC; ++j) fq[j] = A.frq[jbase + min(j, nfc - 1)];
+  const bool active = tid < A.nlev;
+  const int64_t off = prof * A.nlev + (active ? tid : 0);
+  const double pi = A.p[off], ti = A.t[off], rhi = A.rh[off];
+  double awet[NFC], adry[NFC];
+  const double e = goff_gratch_e(ti, rhi);
+  const LevelState L = level_state(pi, ti, e);
+  h2o_absorb<NFC>(A.M, L, fq, awet);
+  dry_absorb<NFC>(A.M, L, fq, adry);
+  if (active) {
+#pragma unroll
+    for (int j = 0; j < NFC; ++j) {
+      if (j < nfc) {
+        const int64_t o = (prof * A.nf + jbase + j) * A.nlev + tid;
+        A.awet[o] = awet[j];
+        A.adry[o] = adry[j];
+      }
+    }
+  }
+}
+
+}  // namespace mwrt

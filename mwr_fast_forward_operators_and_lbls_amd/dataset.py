@@ -1,0 +1,65 @@
+"""Minimal stand-in for the slice of ``xarray.Dataset`` the reference wrapper touches.
+
+The wrapper only does ``ds["name"].values``, ``ds["name"] = (dims, array)``,
+``ds["name"].attrs = {...}`` (python_src/proc/PyRTlib_processing.py:99-114, :161-195) plus
+``xr.open_dataset`` / ``ds.to_netcdf`` (:205, :211).  xarray / netCDF4 are not in this image, so
+batches travel as ``.npz`` here; a real ``xarray.Dataset`` works unchanged with
+``derive_TBs4PyRTlib`` because only that duck-typed subset is used.
+"""
+from __future__ import annotations
+
+import json
+from typing import Dict, Tuple
+
+import numpy as np
+
+
+class Variable:
+    def __init__(self, dims: Tuple[str, ...], values, attrs=None):
+        self.dims = tuple(dims)
+        self.values = np.asarray(values)
+        self.attrs = dict(attrs or {})
+        if self.values.ndim != len(self.dims):
+            raise ValueError(f"dims {self.dims} do not match array of rank {self.values.ndim}")
+
+    @property
+    def shape(self):
+        return self.values.shape
+
+
+class Dataset:
+    def __init__(self, variables: Dict[str, Tuple[Tuple[str, ...], np.ndarray]] = None, attrs=None):
+        self._vars: Dict[str, Variable] = {}
+        self.attrs = dict(attrs or {})
+        for k, v in (variables or {}).items():
+            self[k] = v
+
+    def __getitem__(self, name: str) -> Variable:
+        return self._vars[name]
+
+    def __setitem__(self, name: str, value):
+        if isinstance(value, Variable):
+            self._vars[name] = value
+        else:
+            dims, arr = value
+            self._vars[name] = Variable(dims, arr)
+
+    def __contains__(self, name):
+        return name in self._vars
+
+    def keys(self):
+        return self._vars.keys()
+
+    def to_npz(self, path: str):
+        payload = {k: v.values for k, v in self._vars.items()}
+        meta = {k: {"dims": list(v.dims), "attrs": v.attrs} for k, v in self._vars.items()}
+        np.savez_compressed(path, __meta__=np.array(json.dumps({"vars": meta, "attrs": self.attrs})), **payload)
+
+    @classmethod
+    def from_npz(cls, path: str) -> "Dataset":
+        with np.load(path, allow_pickle=False) as f:
+            meta = json.loads(str(f["__meta__"]))
+            ds = cls(attrs=meta.get("attrs"))
+            for k, m in meta["vars"].items():
+                ds._vars[k] = Variable(tuple(m["dims"]), f[k], m.get("attrs"))
+        return ds

@@ -1,0 +1,149 @@
+#!/usr/bin/env python3
+"""Wrapper-level call surface: ``derive_TBs4PyRTlib(ds, args) -> ds``.
+
+Mirror of reference python_src/proc/PyRTlib_processing.py:83-197 (same function names,
+argument meaning, output variable names / dims / attrs, NaN behaviour and CLI flags), with the
+triple Python loop over (time, Crop, elevation) x 4 models (:99-151, 41 600 ``execute()`` calls
+on the real data set) replaced by ONE batched HIP call per model: all (time, Crop) profiles are
+packed once into contiguous ``[nprof][nlev]`` ground->top arrays and all elevations ride in the
+same launch (absorption is angle-independent, so it is evaluated once instead of 10 times).
+
+Input contract (producer: preprocessing4all.py:807-814, :1195-1203): ``Level_z`` [m],
+``Level_Pressure`` [hPa], ``Level_Temperature`` [K], ``Level_RH`` [%], dims
+``(N_Levels, time, Crop)``, index 0 = top; ``elevation`` [deg].
+Output: ``TBs_PyRTlib_{R24,R17,R98,R20}`` dims ``(time, N_Channels, elevation, Crop)``.
+"""
+from __future__ import annotations
+
+import argparse
+import os
+
+import numpy as np
+
+from ._native import default_context
+from .dataset import Dataset
+from . import spectroscopy
+
+##############################################################################
+# Parameters (reference :35-37)
+##############################################################################
+n_levels = 180
+batch_size = 20
+elevations = np.array([90., 30, 19.2, 14.4, 11.4, 8.4, 6.6, 5.4, 4.8, 4.2])
+
+#: (output suffix, model) in the order the reference evaluates them (:121-151)
+MODEL_RUNS = (("R20", "R20"), ("R24", "R24"), ("R17", "R17"), ("R98", "R98"))
+
+
+def parse_arguments(argv=None):
+    """Same flags as the reference (:43-65): --input/-i, --output/-o."""
+    parser = argparse.ArgumentParser(
+        description="This script processes radiosondes into R24 TBs via the MI355X LBL operator")
+    outpath = "~/PhD_data/TB_preproc_and_proc_results/"
+    outfile = "3_campaigns_PyRTlib_R24_processed_TBs_from_rs.nc"
+    parser.add_argument("--input", "-i", type=str,
+                        default=os.path.expanduser(outpath + "MWR_rs_FESSTVaLSoclesVital1_all_elevations.nc"),
+                        help="NetCDF (needs xarray) or .npz file with rs and MWR data")
+    parser.add_argument("--output", "-o", type=str, default=os.path.expanduser(outpath + outfile),
+                        help="Where to save summarized inputs and output TBs")
+    return parser.parse_args(argv)
+
+
+def check_for_nans(z_in, p_in, t_in, rh_in, frqs, ang):
+    """Reference :71-79 -- True if any input holds a NaN."""
+    return bool(np.any([np.isnan(z_in).any(), np.isnan(p_in).any(), np.isnan(t_in).any(),
+                        np.isnan(rh_in).any(), np.isnan(frqs).any(), np.isnan(ang).any()]))
+
+
+def pack_profiles(ds):
+    """(N_Levels, time, Crop) top->ground  ->  four ``[time*Crop][N_Levels]`` ground->top arrays.
+
+    Applies the wrapper's unit conversions (RH % -> fraction :109, z m -> km :111) and the
+    ``[::-1]`` reversal (:123) once for the whole data set.
+    """
+    def grab(name, scale):
+        a = np.asarray(ds[name].values, dtype=np.float64)
+        if a.ndim != 3:
+            raise ValueError(f"{name}: expected dims (N_Levels, time, Crop)")
+        a = a[::-1, :, :] * scale if scale != 1.0 else a[::-1, :, :]
+        nlev, ntime, ncrop = a.shape
+        return np.ascontiguousarray(a.reshape(nlev, ntime * ncrop).T), ntime, ncrop
+
+    rh, ntime, ncrop = grab("Level_RH", 1.0)
+    rh = rh / 100
+    z, _, _ = grab("Level_z", 1.0)
+    z = z / 1000
+    p, _, _ = grab("Level_Pressure", 1.0)
+    t, _, _ = grab("Level_Temperature", 1.0)
+    return z, p, t, rh, ntime, ncrop
+
+
+def _attrs(tag):
+    return {
+        'long_name': f'Brightness temperature modelled by {tag}',
+        'units': 'K',
+        'standard_name': 'brightness_temperature',
+        'comments': 'Brightness temperatures modeled from radiosonde data for 14 channels of HATPRO radiometer',
+    }
+
+
+def derive_TBs4PyRTlib(ds, args=None, _engine=None):
+    """Reference :83-197.  ``_engine`` is a test seam (tests inject the CPU oracle to exercise the
+    packing logic without a GPU); the default engine is the HIP library and nothing else."""
+    frqs = np.array([22.24, 23.04, 23.84, 25.44, 26.24, 27.84, 31.4, 51.26, 52.28,
+                     53.86, 54.94, 56.66, 57.3, 58.])
+    nf = len(frqs)
+    ang = np.asarray(ds["elevation"].values, dtype=np.float64)
+    nang = len(ang)
+    z, p, t, rh, ntime, ncrop = pack_profiles(ds)
+    nprof = ntime * ncrop
+
+    results = {}
+    for suffix, mdl in MODEL_RUNS:
+        tables = spectroscopy.get_model(mdl)
+        if _engine is not None:
+            tb, valid, _ = _engine(tables, z, p, t, rh, frqs, ang)
+        else:
+            tb, valid = default_context().tb_batch(tables, z, p, t, rh, frqs, ang)
+        bad = np.nonzero(valid == 2)[0]
+        if bad.size:     # the reference does not catch pyrtlib's exception (:123-127)
+            raise ValueError("Error encountered in exponential_integration "
+                             f"(profile index {int(bad[0])}, model {mdl})")
+        # [nprof][nang][nf] -> (time, nf, nang, Crop); profiles were packed time-major, Crop-minor
+        out = tb.reshape(ntime, ncrop, nang, nf).transpose(0, 3, 2, 1)
+        results[suffix] = np.ascontiguousarray(out)
+    nbad = int((valid == 0).sum())
+    for _ in range(nbad * nang):
+        print("NaNs found!!!!!!!")       # reference :153-154 prints once per (time, Crop, elevation)
+
+    for tag in ("R24", "R17", "R98", "R20"):          # reference assignment order :161-195
+        name = "TBs_PyRTlib_" + tag
+        ds[name] = (('time', 'N_Channels', 'elevation', 'Crop'), results[tag])
+        ds[name].attrs = _attrs(tag)
+    return ds
+
+
+def open_dataset(path: str):
+    """``xr.open_dataset`` when xarray is importable (:205), else the .npz exchange format."""
+    if path.endswith(".npz"):
+        return Dataset.from_npz(path)
+    try:
+        import xarray as xr
+    except ImportError as exc:
+        raise ImportError("reading NetCDF needs xarray/netCDF4, which this image lacks; "
+                          "convert to .npz (dataset.Dataset.to_npz)") from exc
+    return xr.open_dataset(path)
+
+
+def write_dataset(ds, path: str):
+    if isinstance(ds, Dataset):
+        ds.to_npz(path if path.endswith(".npz") else path + ".npz")
+    else:
+        ds.to_netcdf(path, format="NETCDF4_CLASSIC")      # reference :211
+
+
+if __name__ == "__main__":
+    args = parse_arguments()
+    ds = open_dataset(args.input)
+    ds = derive_TBs4PyRTlib(ds, args)
+    write_dataset(ds, args.output)

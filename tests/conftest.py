@@ -1,0 +1,58 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def native_lib():
+    """libmwrt.so, built on demand (hipcc cross-compiles gfx950 without a GPU)."""
+    from mwr_fast_forward_operators_and_lbls_amd import build, _native
+    build.build_native()
+    return _native.load_library()
+
+
+@pytest.fixture(scope="session")
+def gpu_ctx(native_lib):
+    from mwr_fast_forward_operators_and_lbls_amd import _native
+    if _native.device_count() < 1:
+        pytest.fail("gpu-marked test started without a GPU: the HIP path has no fallback")
+    ctx = _native.Context(0)
+    yield ctx
+    ctx.close()
+
+
+def oracle_engine(tables, z, p, t, rh, frq, ang):
+    """Test seam for host-logic tests on CPU: the oracle behind the engine signature."""
+    import numpy as np
+    from oracle import lbl_oracle
+    nprof = z.shape[0]
+    nf, nang = len(frq), len(ang)
+    tb = np.full((nprof, nang, nf), np.nan)
+    valid = np.ones(nprof, dtype=np.uint8)
+    ex = {k: np.full((nprof, nang, nf), np.nan) for k in ("tbatm", "tmr", "tauwet", "taudry")}
+    ex["taulay"] = np.full((nprof, nf, z.shape[1]), np.nan)
+    bad_global = np.isnan(frq).any() or np.isnan(ang).any()
+    for i in range(nprof):
+        if bad_global or any(np.isnan(a[i]).any() for a in (z, p, t, rh)):
+            valid[i] = 0
+            continue
+        try:
+            r = lbl_oracle.tb_cloud_rte(tables, z[i], p[i], t[i], rh[i], frq, ang)
+        except ValueError:
+            valid[i] = 2
+            continue
+        tb[i] = r["tbtotal"].reshape(nang, nf)
+        for k in ("tbatm", "tmr", "tauwet", "taudry"):
+            ex[k][i] = r[k].reshape(nang, nf)
+        zen = r["taulay"][:, 0, :] * np.sin(ang[0] * np.pi / 180)
+        ex["taulay"][i] = zen
+    return tb, valid, ex

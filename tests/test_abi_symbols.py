@@ -1,0 +1,63 @@
+"""The C-ABI library loads without a GPU and exports every symbol include/mwrt.h declares."""
+import ctypes
+import os
+import re
+
+import pytest
+
+from mwr_fast_forward_operators_and_lbls_amd import _native, spectroscopy as sp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_symbols():
+    text = open(os.path.join(ROOT, "include", "mwrt.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(mwrt_[a-z_0-9]+)\s*\(", text)))
+
+
+def test_header_declares_expected_surface():
+    syms = declared_symbols()
+    for s in ("mwrt_create", "mwrt_destroy", "mwrt_model_create", "mwrt_tb_batch", "mwrt_tb_batch_device",
+              "mwrt_absorption_batch", "mwrt_last_error", "mwrt_device_count", "mwrt_version"):
+        assert s in syms
+
+
+def test_library_exports_every_declared_symbol(native_lib):
+    for s in declared_symbols():
+        assert hasattr(native_lib, s), f"{s} declared in include/mwrt.h but not exported"
+    assert set(declared_symbols()) == set(_native.SIGNATURES), "binding table out of step with the header"
+
+
+def test_version_and_struct_layout(native_lib):
+    assert native_lib.mwrt_version() == 100
+    assert native_lib.mwrt_model_desc_size() == ctypes.sizeof(sp.MwrtModelDesc)
+    c = sp.get_model("R24").to_c()
+    assert c.n_o2 == 49 and c.n_h2o == 16
+    assert c.o2_f[0] == 118.7503 and c.h2o_fl[0] == 22.23508
+    assert c.o2_dnu1[37] == -0.0004 and c.h2o_d2s[1] == 0.16e-3
+
+
+def test_no_device_means_loud_failure(native_lib):
+    """No CPU fallback: without a GPU, context creation must fail with MWRT_ERR_NO_DEVICE."""
+    if native_lib.mwrt_device_count() > 0:
+        pytest.skip("a GPU is present")
+    with pytest.raises(_native.MwrtError) as ei:
+        _native.Context(0)
+    assert ei.value.code == -2
+    h = ctypes.c_void_p()
+    assert native_lib.mwrt_create(0, ctypes.byref(h)) == -2
+    assert b"no CPU path" in native_lib.mwrt_last_error()
+    # NULL handles are rejected, not dereferenced
+    assert native_lib.mwrt_synchronize(None, None) == -1
+    assert native_lib.mwrt_destroy(None) == 0
+
+
+def test_product_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, "mwr_fast_forward_operators_and_lbls_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for fn in files:
+            if fn.endswith((".py", ".hip", ".h")):
+                src = open(os.path.join(dirpath, fn)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M), fn
+                assert "lbl_oracle" not in src, fn

@@ -1,0 +1,232 @@
+"""Parity tests proper: the HIP path, called through the C ABI, against the oracle.
+
+Tolerance: |dTB| <= 1e-6 K GPU-vs-oracle (both float64; the GPU uses v_rcp_f64+Newton division
+and exp(x ln t) for powers).  The north-star budget vs pyrtlib is 0.01 K -- and that parity is
+UNPINNED (oracle/lbl_oracle.py header)."""
+import os
+
+import numpy as np
+import pytest
+
+from mwr_fast_forward_operators_and_lbls_amd import profiles as pr, spectroscopy as sp
+from oracle import lbl_oracle as lo
+
+pytestmark = pytest.mark.gpu
+
+TOL_K = 1e-6
+MODELS = ["R98", "R17", "R20", "R20SD", "R24"]
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "lbl_golden_v1.npz")
+
+
+def oracle_tb(m, P, i, frq, ang):
+    r = lo.tb_cloud_rte(m, P["z"][i], P["p"][i], P["t"][i], P["rh"][i], frq, ang)
+    return {k: r[k].reshape(len(ang), len(frq)) for k in ("tbtotal", "tbatm", "tmr", "tauwet", "taudry")}, r["taulay"]
+
+
+@pytest.mark.parametrize("name", MODELS)
+@pytest.mark.parametrize("ang", [np.array([90.0]), pr.BENCH_ELEVATIONS_7, pr.REFERENCE_ELEVATIONS],
+                         ids=["zenith", "7elev", "10elev"])
+def test_tb_matches_oracle(gpu_ctx, name, ang):
+    P = pr.synthetic_profiles(5, 21)
+    frq = pr.HATPRO_FRQS
+    tb, valid, ex = gpu_ctx.tb_batch(name, P["z"], P["p"], P["t"], P["rh"], frq, ang, extras=True)
+    assert valid.tolist() == [1] * 5
+    m = sp.get_model(name)
+    for i in (0, 3):
+        ref, taulay = oracle_tb(m, P, i, frq, ang)
+        assert np.abs(tb[i] - ref["tbtotal"]).max() <= TOL_K
+        assert np.abs(ex["tbatm"][i] - ref["tbatm"]).max() <= TOL_K
+        assert np.abs(ex["tmr"][i] - ref["tmr"]).max() <= TOL_K
+        assert np.allclose(ex["tauwet"][i], ref["tauwet"], rtol=1e-9)
+        assert np.allclose(ex["taudry"][i], ref["taudry"], rtol=1e-9)
+        zen = taulay[:, 0, :] * np.sin(ang[0] * np.pi / 180)
+        assert np.allclose(ex["taulay"][i], zen, rtol=1e-9, atol=1e-16)
+
+
+@pytest.mark.parametrize("name", MODELS)
+def test_golden_vectors(gpu_ctx, name):
+    with np.load(GOLD, allow_pickle=False) as f:
+        g = {k: f[k] for k in f.files}
+    tb, valid, ex = gpu_ctx.tb_batch(name, g["z"], g["p"], g["t"], g["rh"], g["frq"], g["ang"], extras=True)
+    assert (valid == 1).all()
+    assert np.abs(tb - g[f"{name}_tbtotal"]).max() <= TOL_K
+    assert np.abs(ex["tbatm"] - g[f"{name}_tbatm"]).max() <= TOL_K
+    assert np.abs(ex["tmr"] - g[f"{name}_tmr"]).max() <= TOL_K
+    assert np.allclose(ex["tauwet"], g[f"{name}_tauwet"], rtol=1e-9)
+    assert np.allclose(ex["taudry"], g[f"{name}_taudry"], rtol=1e-9)
+    aw, ad = gpu_ctx.absorption_batch(name, g["p"], g["t"], g["rh"], g["frq"])
+    assert np.allclose(aw[1], g[f"{name}_awet"], rtol=1e-9)
+    assert np.allclose(ad[1], g[f"{name}_adry"], rtol=1e-9)
+
+
+@pytest.mark.parametrize("nf", [1, 7, 8, 9, 14, 15, 16, 17, 28, 33])
+def test_frequency_chunking(gpu_ctx, nf):
+    """Every chunk width (8 / 14 / 16 lanes of accumulators) and ragged tails agree with the oracle."""
+    P = pr.synthetic_profiles(2, 22, nlev=60)
+    frq = np.linspace(20.0, 60.0, nf) if nf > 1 else np.array([31.4])
+    ang = np.array([90.0, 10.0])
+    tb, valid = gpu_ctx.tb_batch("R24", P["z"], P["p"], P["t"], P["rh"], frq, ang)
+    ref, _ = oracle_tb(sp.get_model("R24"), P, 1, frq, ang)
+    assert np.abs(tb[1] - ref["tbtotal"]).max() <= TOL_K
+    aw, ad = gpu_ctx.absorption_batch("R24", P["p"], P["t"], P["rh"], frq)
+    ow, od = lo.absorption_profile(sp.get_model("R24"), P["p"][1], P["t"][1], P["rh"][1], frq)
+    assert np.allclose(aw[1], ow, rtol=1e-9) and np.allclose(ad[1], od, rtol=1e-9)
+
+
+@pytest.mark.parametrize("nlev", [20, 63, 64, 65, 128, 192, 256, 257, 600, 1024])
+def test_level_counts(gpu_ctx, nlev):
+    """Ragged level counts across the wave (64) and launch-bound (256 / 1024) edges."""
+    P = pr.synthetic_profiles(3, 23, nlev=nlev)
+    ang = np.array([90.0, 30.0, 5.4])
+    tb, valid = gpu_ctx.tb_batch("R20", P["z"], P["p"], P["t"], P["rh"], pr.HATPRO_FRQS, ang)
+    assert (valid == 1).all()
+    ref, _ = oracle_tb(sp.get_model("R20"), P, 2, pr.HATPRO_FRQS, ang)
+    assert np.abs(tb[2] - ref["tbtotal"]).max() <= TOL_K
+
+
+def test_two_level_profile_and_limits(gpu_ctx):
+    from mwr_fast_forward_operators_and_lbls_amd._native import MwrtError
+    z = np.array([[0.1, 1.0]]); p = np.array([[1000.0, 900.0]]); t = np.array([[290.0, 284.0]]); rh = np.array([[0.5, 0.4]])
+    tb, valid = gpu_ctx.tb_batch("R98", z, p, t, rh, pr.HATPRO_FRQS, np.array([90.0]))
+    ref = lo.tb_cloud_rte(sp.get_model("R98"), z[0], p[0], t[0], rh[0], pr.HATPRO_FRQS, np.array([90.0]))["tbtotal"]
+    assert np.abs(tb[0, 0] - ref).max() <= TOL_K
+    with pytest.raises(MwrtError) as ei:
+        gpu_ctx.tb_batch("R98", z[:, :1], p[:, :1], t[:, :1], rh[:, :1], pr.HATPRO_FRQS, np.array([90.0]))
+    assert ei.value.code == -1
+    big = np.ones((1, 1025))
+    with pytest.raises(MwrtError) as ei:
+        gpu_ctx.tb_batch("R98", big, big, big, big, pr.HATPRO_FRQS, np.array([90.0]))
+    assert ei.value.code == -5
+    tb0, v0 = gpu_ctx.tb_batch("R98", np.zeros((0, 10)), np.zeros((0, 10)), np.zeros((0, 10)), np.zeros((0, 10)),
+                               pr.HATPRO_FRQS, np.array([90.0]))
+    assert tb0.shape == (0, 1, 14) and v0.shape == (0,)
+
+
+def test_nan_in_nan_out(gpu_ctx):
+    """check_for_nans contract (PyRTlib_processing.py:71-79, :117-119): a NaN anywhere in a profile
+    leaves that profile's TBs NaN and touches nobody else; NaN in frqs/ang blanks everything."""
+    P = pr.synthetic_profiles(8, 24)
+    ang = pr.BENCH_ELEVATIONS_7
+    clean, _ = gpu_ctx.tb_batch("R24", P["z"], P["p"], P["t"], P["rh"], pr.HATPRO_FRQS, ang)
+    for fld, prof, lev in (("z", 0, 0), ("p", 2, 179), ("t", 5, 90), ("rh", 7, 64)):
+        Q = {k: v.copy() for k, v in P.items()}
+        Q[fld][prof, lev] = np.nan
+        tb, valid, ex = gpu_ctx.tb_batch("R24", Q["z"], Q["p"], Q["t"], Q["rh"], pr.HATPRO_FRQS, ang, extras=True)
+        assert valid[prof] == 0 and np.isnan(tb[prof]).all() and np.isnan(ex["tauwet"][prof]).all()
+        keep = np.arange(8) != prof
+        assert (valid[keep] == 1).all() and np.array_equal(tb[keep], clean[keep])
+    f = pr.HATPRO_FRQS.copy(); f[3] = np.nan
+    tb, valid = gpu_ctx.tb_batch("R24", P["z"], P["p"], P["t"], P["rh"], f, ang)
+    assert np.isnan(tb).all() and (valid == 0).all()
+    a = ang.copy(); a[0] = np.nan
+    tb, valid = gpu_ctx.tb_batch("R24", P["z"], P["p"], P["t"], P["rh"], pr.HATPRO_FRQS, a)
+    assert np.isnan(tb).all() and (valid == 0).all()
+
+
+def test_negative_absorption_is_flagged(gpu_ctx):
+    import dataclasses
+    bad = dataclasses.replace(sp.get_model("R98"), name="R98_negcont_gpu", h2o_cf=-1e-6)
+    P = pr.synthetic_profiles(2, 25, nlev=40)
+    tb, valid = gpu_ctx.tb_batch(bad, P["z"], P["p"], P["t"], P["rh"], pr.HATPRO_FRQS, np.array([90.0]))
+    assert (valid == 2).all() and np.isnan(tb).all()
+    with pytest.raises(ValueError):
+        lo.tb_cloud_rte(bad, P["z"][0], P["p"][0], P["t"][0], P["rh"][0], pr.HATPRO_FRQS, np.array([90.0]))
+    # negative rh only zeroes the wet term, on both sides
+    tb, valid = gpu_ctx.tb_batch("R98", P["z"], P["p"], P["t"], -P["rh"], pr.HATPRO_FRQS, np.array([90.0]))
+    ref = lo.tb_cloud_rte(sp.get_model("R98"), P["z"][0], P["p"][0], P["t"][0], -P["rh"][0], pr.HATPRO_FRQS,
+                          np.array([90.0]))["tbtotal"]
+    assert valid[0] == 1 and np.abs(tb[0, 0] - ref).max() <= TOL_K
+
+
+def test_isothermal_and_dry_known_answers(gpu_ctx):
+    """Size-independent physics on the GPU path itself."""
+    nlev = 100
+    z = np.linspace(0.0, 30.0, nlev)[None, :]
+    p = 1000.0 * np.exp(-z / 7.5)
+    t = np.full_like(z, 275.0)
+    rh = np.full_like(z, 0.6)
+    tb, valid, ex = gpu_ctx.tb_batch("R24", z, p, t, rh, pr.HATPRO_FRQS, np.array([90.0, 4.2]), extras=True)
+    m = sp.get_model("R24")
+    tau = ex["tauwet"] + ex["taudry"]
+    hvk = pr.HATPRO_FRQS * 1e9 * m.planck_h / m.boltzmann_k
+    B = 1 / (np.exp(hvk / 275.0) - 1); Bc = 1 / (np.exp(hvk / m.t_cosmic) - 1)
+    expect = hvk / np.log(1 + 1 / (B * (1 - np.exp(-tau)) + Bc * np.exp(-tau)))
+    assert np.abs(tb - expect).max() < 1e-7
+    assert np.allclose(tau[0, 1] / tau[0, 0], 1 / np.sin(4.2 * np.pi / 180), rtol=1e-12)
+    assert np.abs(ex["tmr"] - 275.0).max() < 1e-6
+
+
+def test_full_size_properties_config3(gpu_ctx):
+    """BASELINE config 3 (1000 x 14 x 7) through size-independent properties: batch-slicing,
+    permutation and angle-subset invariance are BITWISE; physical bounds hold; a sample is
+    checked against the oracle."""
+    P = pr.synthetic_profiles(1000, 3)
+    frq, ang = pr.HATPRO_FRQS, pr.BENCH_ELEVATIONS_7
+    tb, valid = gpu_ctx.tb_batch("R24", P["z"], P["p"], P["t"], P["rh"], frq, ang)
+    assert tb.shape == (1000, 7, 14) and (valid == 1).all() and np.isfinite(tb).all()
+    tb2, _ = gpu_ctx.tb_batch("R24", P["z"], P["p"], P["t"], P["rh"], frq, ang)
+    assert np.array_equal(tb, tb2)                                      # deterministic
+    sl = slice(400, 437)
+    tbs, _ = gpu_ctx.tb_batch("R24", P["z"][sl], P["p"][sl], P["t"][sl], P["rh"][sl], frq, ang)
+    assert np.array_equal(tbs, tb[sl])                                  # batch-size independent
+    perm = np.random.default_rng(0).permutation(1000)
+    tbp, _ = gpu_ctx.tb_batch("R24", P["z"][perm], P["p"][perm], P["t"][perm], P["rh"][perm], frq, ang)
+    assert np.array_equal(tbp, tb[perm])                                # profile order is irrelevant
+    tba, _ = gpu_ctx.tb_batch("R24", P["z"], P["p"], P["t"], P["rh"], frq, ang[[0, 3, 6]])
+    assert np.abs(tba - tb[:, [0, 3, 6]]).max() <= 1e-10                # angles are independent
+    assert (tb > 2.7).all() and (tb < P["t"].max(axis=1)[:, None, None] + 1e-6).all()
+    assert (np.diff(tb[:, :, :7], axis=1) > 0).all()                    # K band warms towards the horizon
+    m = sp.get_model("R24")
+    for i in (0, 517, 999):
+        ref, _ = oracle_tb(m, P, i, frq, ang)
+        assert np.abs(tb[i] - ref["tbtotal"]).max() <= TOL_K
+
+
+def test_device_pointer_entry(gpu_ctx):
+    """mwrt_tb_batch_device on torch-owned HBM buffers equals the host-buffer entry bitwise."""
+    import torch
+    P = pr.synthetic_profiles(64, 26)
+    ang, frq = pr.BENCH_ELEVATIONS_7, pr.HATPRO_FRQS
+    host, hv = gpu_ctx.tb_batch("R24", P["z"], P["p"], P["t"], P["rh"], frq, ang)
+    dev = torch.device("cuda:0")
+    d = {k: torch.from_numpy(P[k]).to(dev) for k in ("z", "p", "t", "rh")}
+    out = torch.empty((64, 7, 14), dtype=torch.float64, device=dev)
+    val = torch.empty(64, dtype=torch.uint8, device=dev)
+    torch.cuda.synchronize()
+    st = torch.cuda.current_stream().cuda_stream
+    gpu_ctx.tb_batch_device("R24", 64, 180, d["z"].data_ptr(), d["p"].data_ptr(), d["t"].data_ptr(),
+                            d["rh"].data_ptr(), frq, ang, out.data_ptr(), val.data_ptr(), stream=st)
+    torch.cuda.synchronize()
+    assert np.array_equal(out.cpu().numpy(), host) and np.array_equal(val.cpu().numpy(), hv)
+
+
+def test_reference_call_surface_end_to_end(gpu_ctx):
+    """The five lines of PyRTlib_processing.py:123-127, verbatim, on the HIP path."""
+    from mwr_fast_forward_operators_and_lbls_amd.tb_spectrum import TbCloudRTE
+    P = pr.synthetic_profiles(1, 27)
+    z_in, p_in, t_in, rh_in = (P[k][0][::-1].copy() for k in ("z", "p", "t", "rh"))   # top -> ground as in the file
+    frqs = pr.HATPRO_FRQS
+    for mdl in ("R20", "R24", "R17", "R98"):
+        for elevation in (90.0, 4.2):
+            ang = np.array([elevation])
+            rte = TbCloudRTE(z_in[::-1], p_in[::-1], t_in[::-1], rh_in[::-1], frqs, ang)
+            rte.init_absmdl(mdl)
+            rte.satellite = False
+            df_from_ground = rte.execute()
+            ref = lo.tb_cloud_rte(sp.get_model(mdl), P["z"][0], P["p"][0], P["t"][0], P["rh"][0], frqs, ang)["tbtotal"]
+            assert np.abs(df_from_ground["tbtotal"].values - ref).max() <= TOL_K
+
+
+def test_wrapper_end_to_end(gpu_ctx):
+    from test_host_logic import make_ds
+    from conftest import oracle_engine
+    from mwr_fast_forward_operators_and_lbls_amd import pyrtlib_processing as pp
+    ds, _ = make_ds(ntime=3, ncrop=2, nlev=180, elev=tuple(pr.REFERENCE_ELEVATIONS), nan_at=(7, 2, 1))
+    ds2, _ = make_ds(ntime=3, ncrop=2, nlev=180, elev=tuple(pr.REFERENCE_ELEVATIONS), nan_at=(7, 2, 1))
+    out = pp.derive_TBs4PyRTlib(ds, None)
+    ref = pp.derive_TBs4PyRTlib(ds2, None, _engine=oracle_engine)
+    for tag in ("R24", "R17", "R98", "R20"):
+        a, b = out["TBs_PyRTlib_" + tag].values, ref["TBs_PyRTlib_" + tag].values
+        assert a.shape == (3, 14, 10, 2)
+        assert np.array_equal(np.isnan(a), np.isnan(b)) and np.isnan(a[2, :, :, 1]).all()
+        assert np.nanmax(np.abs(a - b)) <= TOL_K
