@@ -59,6 +59,32 @@ SIGNATURES = {
 
 _lib = None
 _lib_lock = threading.Lock()
+_hip_runtime_path = None
+
+
+def _share_hip_runtime_with_torch():
+    """One HIP runtime per process.  PyTorch-ROCm bundles its own libamdhip64.so (SONAME
+    libamdhip64.so.7) and asks for it by the bare file name, so if libmwrt.so pulled in the
+    system copy first, a later ``import torch`` would load a second runtime and find no GPU.
+    Pre-loading torch's copy (when torch is installed) makes libmwrt.so's DT_NEEDED
+    ``libamdhip64.so.7`` resolve to the same object whatever the import order."""
+    global _hip_runtime_path
+    if _hip_runtime_path is not None:
+        return
+    _hip_runtime_path = ""
+    if os.environ.get("MWRT_SYSTEM_HIP", "0") == "1":
+        return
+    try:
+        import importlib.util
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.submodule_search_locations:
+        return
+    cand = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+    if os.path.exists(cand):
+        ctypes.CDLL(cand, mode=ctypes.RTLD_GLOBAL)
+        _hip_runtime_path = cand
 
 
 def load_library(path: Optional[str] = None) -> ctypes.CDLL:
@@ -72,6 +98,7 @@ def load_library(path: Optional[str] = None) -> ctypes.CDLL:
             raise NativeLibraryMissing(
                 f"{p} not built: run `python -c 'import __graft_entry__ as g; g.build()'` "
                 "(hipcc --offload-arch=gfx950). There is no CPU fallback.")
+        _share_hip_runtime_with_torch()
         lib = ctypes.CDLL(p)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(lib, name)

@@ -87,10 +87,12 @@ LaunchGeom plan_k2(int nlev, int npairs, int threads) {
   return g;
 }
 
-template <int NFC>
-size_t fused_lds_bytes(const LaunchGeom& g, int nang, int threads) {
-  return sizeof(double) * ((size_t)2 * NFC * g.ldrow + (size_t)3 * NFC * nang * g.nseg + threads / WAVE + 2);
+size_t fused_lds_bytes(int nfc, const LaunchGeom& g, int nang, int threads) {
+  return sizeof(double) * ((size_t)2 * nfc * g.ldrow + (size_t)3 * nfc * nang * g.nseg + threads / WAVE + 2);
 }
+
+// K2 split for a chunk width, shrunk until the workgroup's LDS fits; false if it cannot
+bool plan_fused(const mwrt_context* c, int nfc, int nlev, int nf, int nang, LaunchGeom* g, size_t* lds);
 
 int upload_small(mwrt_context* c, DevBuf& buf, std::vector<double>& cache, const double* src, int n,
                  hipStream_t st) {
@@ -130,14 +132,10 @@ int launch_fused(mwrt_context* c, FusedArgs a, int64_t nprof, hipStream_t st) {
   const int threads = ((a.nlev + WAVE - 1) / WAVE) * WAVE;
   const int nchunks = (a.nf + NFC - 1) / NFC;
   const int npairs = std::min(NFC, a.nf) * a.nang;
-  a.g = plan_k2(a.nlev, npairs, threads);
-  size_t lds = fused_lds_bytes<NFC>(a.g, a.nang, threads);
-  while (lds > (size_t)c->lds_max && a.g.nseg > 1) {     // shrink the partials if LDS is short
-    a.g.nseg = (a.g.nseg + 1) / 2;
-    a.g.seglen = (a.nlev - 1 + a.g.nseg - 1) / a.g.nseg;
-    lds = fused_lds_bytes<NFC>(a.g, a.nang, threads);
-  }
-  if (lds > (size_t)c->lds_max) return fail(MWRT_ERR_UNSUPPORTED, "LDS budget exceeded (nlev x nang too large)");
+  (void)npairs;
+  size_t lds = 0;
+  if (!plan_fused(c, NFC, a.nlev, a.nf, a.nang, &a.g, &lds))
+    return fail(MWRT_ERR_UNSUPPORTED, "LDS budget exceeded (nlev x nang too large)");
   dim3 grid((unsigned)nprof, (unsigned)nchunks), block(threads);
   timing_begin(c, st);
   if (threads <= 256) {
@@ -167,10 +165,30 @@ int launch_absorb(mwrt_context* c, AbsorbArgs a, int64_t nprof, hipStream_t st) 
   return MWRT_OK;
 }
 
+bool plan_fused(const mwrt_context* c, int nfc, int nlev, int nf, int nang, LaunchGeom* g, size_t* lds) {
+  const int threads = ((nlev + WAVE - 1) / WAVE) * WAVE;
+  *g = plan_k2(nlev, std::min(nfc, nf) * nang, threads);
+  *lds = fused_lds_bytes(nfc, *g, nang, threads);
+  while (*lds > (size_t)c->lds_max && g->nseg > 1) {     // shrink the partials if LDS is short
+    g->nseg = (g->nseg + 1) / 2;
+    g->seglen = (nlev - 1 + g->nseg - 1) / g->nseg;
+    *lds = fused_lds_bytes(nfc, *g, nang, threads);
+  }
+  return *lds <= (size_t)c->lds_max;
+}
+
 // frequency-chunk width: 14 HATPRO channels fit one chunk exactly; other counts use 16 / 8
 int pick_nfc(int nf) {
   if (nf % 14 == 0 || nf <= 14) return (nf <= 8) ? 8 : 14;
   return 16;
+}
+
+// ... unless the profile is so tall that the wide chunk's LDS rows do not fit: then 8
+int pick_nfc_fused(const mwrt_context* c, int nlev, int nf, int nang) {
+  int nfc = pick_nfc(nf);
+  LaunchGeom g; size_t lds;
+  if (!plan_fused(c, nfc, nlev, nf, nang, &g, &lds)) nfc = 8;
+  return nfc;
 }
 
 }  // namespace
@@ -285,7 +303,7 @@ int mwrt_tb_batch_device(mwrt_context* c, const mwrt_model* m, int64_t nprof, in
   a.tb = d_tb; a.valid = d_valid;
   if (ex) { a.tbatm = ex->tbatm; a.tmr = ex->tmr; a.tauwet = ex->tauwet; a.taudry = ex->taudry; a.taulay = ex->taulay; }
   a.nlev = nlev; a.nf = nf; a.nang = nang;
-  switch (pick_nfc(nf)) {
+  switch (pick_nfc_fused(c, nlev, nf, nang)) {
     case 8: return launch_fused<8>(c, a, nprof, st);
     case 14: return launch_fused<14>(c, a, nprof, st);
     default: return launch_fused<16>(c, a, nprof, st);
