@@ -142,9 +142,12 @@ int mwrt_absorption_batch_device(mwrt_context* ctx, const mwrt_model* model,
 /* Block until everything queued on the context's stream (or `stream`) has finished. */
 int mwrt_synchronize(mwrt_context* ctx, void* stream);
 
-/* Average device time, in milliseconds, of the last timed launch on this context:
- * mwrt_set_timing(ctx, 1) brackets every kernel launch with hipEvents on the launch stream. */
+/* Kernel timing with HIP events: mwrt_set_timing(ctx, 1) brackets every kernel launch with a
+ * hipEvent pair recorded on the launch stream (ring of 512 pairs, no host synchronisation).
+ * mwrt_timing_collect sums the device time of the launches since the last collect/enable and
+ * returns how many there were; mwrt_last_kernel_ms reads the most recent one. */
 int mwrt_set_timing(mwrt_context* ctx, int enabled);
+int mwrt_timing_collect(mwrt_context* ctx, double* total_ms, int32_t* launches);
 int mwrt_last_kernel_ms(mwrt_context* ctx, double* ms_out);
 
 #ifdef __cplusplus

@@ -54,6 +54,7 @@ SIGNATURES = {
     "mwrt_absorption_batch_device": (ctypes.c_int, [_vp, _vp, _i64, _i32, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp]),
     "mwrt_synchronize": (ctypes.c_int, [_vp, _vp]),
     "mwrt_set_timing": (ctypes.c_int, [_vp, ctypes.c_int]),
+    "mwrt_timing_collect": (ctypes.c_int, [_vp, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int32)]),
     "mwrt_last_kernel_ms": (ctypes.c_int, [_vp, ctypes.POINTER(ctypes.c_double)]),
 }
 
@@ -239,6 +240,12 @@ class Context:
 
     def set_timing(self, enabled: bool):
         self._check(self._lib.mwrt_set_timing(self._handle, int(bool(enabled))), "mwrt_set_timing")
+
+    def timing_collect(self):
+        """(total device ms, number of launches) since timing was enabled / last collected."""
+        ms, n = ctypes.c_double(), ctypes.c_int32()
+        self._check(self._lib.mwrt_timing_collect(self._handle, ctypes.byref(ms), ctypes.byref(n)), "mwrt_timing_collect")
+        return ms.value, n.value
 
     def last_kernel_ms(self) -> float:
         ms = ctypes.c_double()

@@ -53,11 +53,12 @@ struct mwrt_context {
   std::vector<double> h_frq, h_am;
   // staging for the host-buffer entry points
   DevBuf d_in, d_out, d_valid, d_ex;
-  // timing
+  // timing: a ring of hipEvent pairs recorded around every kernel launch, on the launch stream
   bool timing = false;
-  hipEvent_t ev0 = nullptr, ev1 = nullptr;
-  bool ev_pending = false;
+  std::vector<hipEvent_t> ev0, ev1;
+  long ev_count = 0;
 };
+constexpr int TIMING_RING = 512;
 
 struct mwrt_model {
   mwrt_model_desc* d_desc = nullptr;
@@ -121,10 +122,10 @@ bool any_nan(const double* x, int n) {
 }
 
 void timing_begin(mwrt_context* c, hipStream_t st) {
-  if (c->timing) { (void)hipEventRecord(c->ev0, st); }
+  if (c->timing) (void)hipEventRecord(c->ev0[c->ev_count % TIMING_RING], st);
 }
 void timing_end(mwrt_context* c, hipStream_t st) {
-  if (c->timing) { (void)hipEventRecord(c->ev1, st); c->ev_pending = true; }
+  if (c->timing) { (void)hipEventRecord(c->ev1[c->ev_count % TIMING_RING], st); c->ev_count++; }
 }
 
 template <int NFC>
@@ -222,8 +223,6 @@ int mwrt_create(int device_id, mwrt_context** out) {
   int lds = 0;
   if (hipDeviceGetAttribute(&lds, hipDeviceAttributeMaxSharedMemoryPerBlock, device_id) == hipSuccess && lds > 0)
     c->lds_max = lds;
-  (void)hipEventCreate(&c->ev0);
-  (void)hipEventCreate(&c->ev1);
   *out = c;
   return MWRT_OK;
 }
@@ -234,8 +233,8 @@ int mwrt_destroy(mwrt_context* c) {
   (void)hipStreamSynchronize(c->stream);
   c->d_frq.release(); c->d_am.release(); c->d_in.release(); c->d_out.release();
   c->d_valid.release(); c->d_ex.release();
-  if (c->ev0) (void)hipEventDestroy(c->ev0);
-  if (c->ev1) (void)hipEventDestroy(c->ev1);
+  for (hipEvent_t e : c->ev0) (void)hipEventDestroy(e);
+  for (hipEvent_t e : c->ev1) (void)hipEventDestroy(e);
   (void)hipStreamDestroy(c->stream);
   delete c;
   return MWRT_OK;
@@ -411,17 +410,40 @@ int mwrt_synchronize(mwrt_context* c, void* stream) {
 
 int mwrt_set_timing(mwrt_context* c, int enabled) {
   if (!c) return fail(MWRT_ERR_INVALID_ARGUMENT, "null context");
+  HIP_TRY(hipSetDevice(c->device));
+  if (enabled && c->ev0.empty()) {
+    c->ev0.resize(TIMING_RING); c->ev1.resize(TIMING_RING);
+    for (int i = 0; i < TIMING_RING; ++i) { HIP_TRY(hipEventCreate(&c->ev0[i])); HIP_TRY(hipEventCreate(&c->ev1[i])); }
+  }
   c->timing = enabled != 0;
-  c->ev_pending = false;
+  c->ev_count = 0;
+  return MWRT_OK;
+}
+
+int mwrt_timing_collect(mwrt_context* c, double* total_ms, int32_t* launches) {
+  if (!c || !total_ms || !launches) return fail(MWRT_ERR_INVALID_ARGUMENT, "null argument");
+  HIP_TRY(hipSetDevice(c->device));
+  const long n = c->ev_count < TIMING_RING ? c->ev_count : TIMING_RING;
+  double sum = 0.0;
+  for (long i = 0; i < n; ++i) {
+    HIP_TRY(hipEventSynchronize(c->ev1[i]));
+    float ms = 0.f;
+    HIP_TRY(hipEventElapsedTime(&ms, c->ev0[i], c->ev1[i]));
+    sum += ms;
+  }
+  *total_ms = sum;
+  *launches = (int32_t)n;
+  c->ev_count = 0;
   return MWRT_OK;
 }
 
 int mwrt_last_kernel_ms(mwrt_context* c, double* ms_out) {
   if (!c || !ms_out) return fail(MWRT_ERR_INVALID_ARGUMENT, "null argument");
-  if (!c->ev_pending) return fail(MWRT_ERR_INVALID_ARGUMENT, "no timed launch pending");
-  HIP_TRY(hipEventSynchronize(c->ev1));
+  if (c->ev_count < 1) return fail(MWRT_ERR_INVALID_ARGUMENT, "no timed launch pending");
+  const long i = (c->ev_count - 1) % TIMING_RING;
+  HIP_TRY(hipEventSynchronize(c->ev1[i]));
   float ms = 0.f;
-  HIP_TRY(hipEventElapsedTime(&ms, c->ev0, c->ev1));
+  HIP_TRY(hipEventElapsedTime(&ms, c->ev0[i], c->ev1[i]));
   *ms_out = ms;
   return MWRT_OK;
 }

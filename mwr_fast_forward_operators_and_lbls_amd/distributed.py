@@ -1,0 +1,83 @@
+"""Multi-GPU execution of the hot path: independent profile shards + one final TB gather.
+
+Every profile's TBs depend on that profile only (the reference's loops carry no state between
+iterations and write disjoint slots, python_src/proc/PyRTlib_processing.py:99-101, :127), so
+the batch is cut into contiguous blocks of profiles, one block per rank (one process per GPU),
+with NO collective on the data path.  The only exchange is the final gather of the
+``[nprof][nang][nf]`` result shards -- ``torch.distributed.all_gather`` (backend "nccl" is RCCL on
+ROCm, riding xGMI; "gloo" in the CPU tests).  Payloads are tiny against xGMI (config 4:
+0.98 MB per GPU), so a single un-bucketed call is right; see DESIGN.md section 6.
+"""
+from __future__ import annotations
+
+from typing import Optional, Tuple
+
+import numpy as np
+
+
+def shard_bounds(nprof: int, world_size: int, rank: int) -> Tuple[int, int]:
+    """Contiguous block ``[lo, hi)`` of rank ``rank``: ceil(nprof/world) profiles per rank, the
+    tail ranks may be short or empty."""
+    if world_size < 1 or not (0 <= rank < world_size):
+        raise ValueError("bad world_size / rank")
+    per = -(-nprof // world_size)
+    lo = min(rank * per, nprof)
+    return lo, min(lo + per, nprof)
+
+
+def gather_shards(local, nprof_total: int, group=None):
+    """All-gather equal-padded shards and trim: returns the full array on every rank.
+
+    ``local`` is a torch tensor ``[n_local, ...]`` (device tensor under nccl/RCCL, CPU under
+    gloo); shards are padded to ceil(nprof/world) rows so one collective moves everything."""
+    import torch
+    import torch.distributed as dist
+
+    world = dist.get_world_size(group)
+    per = -(-nprof_total // world)
+    pad = torch.full((per,) + tuple(local.shape[1:]), float("nan"), dtype=local.dtype, device=local.device) \
+        if local.dtype.is_floating_point else torch.zeros((per,) + tuple(local.shape[1:]), dtype=local.dtype,
+                                                          device=local.device)
+    pad[: local.shape[0]] = local
+    parts = [torch.empty_like(pad) for _ in range(world)]
+    dist.all_gather(parts, pad, group=group)
+    return torch.cat(parts, dim=0)[:nprof_total]
+
+
+def tb_batch_sharded(model, z, p, t, rh, frq, ang, group=None, device_id: Optional[int] = None, _engine=None):
+    """Evaluate a GLOBAL batch (same arrays on every rank) across the ranks of ``group``.
+
+    Each rank computes its contiguous block with the HIP library on its own GPU and the blocks
+    are gathered once.  Returns ``(tb [nprof][nang][nf], valid [nprof])`` as NumPy arrays on
+    every rank.  ``_engine`` is the CPU test seam (gloo tests inject the oracle)."""
+    import torch
+    import torch.distributed as dist
+
+    rank, world = dist.get_rank(group), dist.get_world_size(group)
+    z = np.asarray(z)
+    nprof = z.shape[0]
+    lo, hi = shard_bounds(nprof, world, rank)
+    frq = np.asarray(frq, dtype=np.float64)
+    ang = np.asarray(ang, dtype=np.float64)
+    nf, nang = len(frq), len(ang)
+    use_gpu = _engine is None
+    dev = torch.device("cuda", device_id if device_id is not None else torch.cuda.current_device()) if use_gpu \
+        else torch.device("cpu")
+    if hi > lo:
+        sl = slice(lo, hi)
+        if use_gpu:
+            from ._native import default_context
+            tb, valid = default_context(dev.index).tb_batch(model, z[sl], np.asarray(p)[sl], np.asarray(t)[sl],
+                                                            np.asarray(rh)[sl], frq, ang)
+        else:
+            from . import spectroscopy
+            tables = spectroscopy.get_model(model) if isinstance(model, str) else model
+            tb, valid, _ = _engine(tables, np.ascontiguousarray(z[sl]), np.ascontiguousarray(np.asarray(p)[sl]),
+                                   np.ascontiguousarray(np.asarray(t)[sl]), np.ascontiguousarray(np.asarray(rh)[sl]),
+                                   frq, ang)
+    else:
+        tb = np.empty((0, nang, nf))
+        valid = np.empty(0, dtype=np.uint8)
+    tb_all = gather_shards(torch.from_numpy(np.ascontiguousarray(tb)).to(dev), nprof, group)
+    valid_all = gather_shards(torch.from_numpy(np.ascontiguousarray(valid)).to(dev), nprof, group)
+    return tb_all.cpu().numpy(), valid_all.cpu().numpy()
