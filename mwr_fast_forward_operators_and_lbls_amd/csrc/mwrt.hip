@@ -61,8 +61,8 @@ struct mwrt_context {
 constexpr int TIMING_RING = 512;
 
 struct mwrt_model {
-  mwrt_model_desc* d_desc = nullptr;
-  mwrt_model_desc h_desc;
+  ModelFlat* d_desc = nullptr;
+  ModelFlat h_desc;
 };
 
 namespace {
@@ -248,9 +248,11 @@ int mwrt_model_create(mwrt_context* c, const mwrt_model_desc* desc, mwrt_model**
   HIP_TRY(hipSetDevice(c->device));
   mwrt_model* m = new (std::nothrow) mwrt_model();
   if (!m) return fail(MWRT_ERR_OUT_OF_MEMORY, "host allocation failed");
-  m->h_desc = *desc;
-  hipError_t e = hipMalloc((void**)&m->d_desc, sizeof(mwrt_model_desc));
-  if (e == hipSuccess) e = hipMemcpy(m->d_desc, desc, sizeof(mwrt_model_desc), hipMemcpyHostToDevice);
+  static_cast<mwrt_model_desc&>(m->h_desc) = *desc;
+  for (int k = 0; k < MWRT_MAX_O2_LINES; ++k)
+    m->h_desc.o2_rf2[k] = (k < desc->n_o2 && desc->o2_f[k] != 0.0) ? 1.0 / (desc->o2_f[k] * desc->o2_f[k]) : 0.0;
+  hipError_t e = hipMalloc((void**)&m->d_desc, sizeof(ModelFlat));
+  if (e == hipSuccess) e = hipMemcpy(m->d_desc, &m->h_desc, sizeof(ModelFlat), hipMemcpyHostToDevice);
   if (e != hipSuccess) { if (m->d_desc) (void)hipFree(m->d_desc); delete m; return fail(MWRT_ERR_HIP, hipGetErrorString(e)); }
   *out = m;
   return MWRT_OK;

@@ -22,6 +22,16 @@ namespace mwrt {
 constexpr int WAVE = 64;
 constexpr double TAUMAX = 125.0;
 
+// Device image of the tables: the ABI record plus host-precomputed reciprocals.  It is read
+// through a CONSTANT-address-space pointer: the tables never change while a kernel runs, and
+// that is what lets the compiler fetch them with s_load (scalar cache, SGPR operands) instead of
+// 64 identical vector loads per wave.
+struct ModelFlat : mwrt_model_desc {
+  double o2_rf2[MWRT_MAX_O2_LINES];      // 1 / F_k^2
+};
+typedef const __attribute__((address_space(4))) ModelFlat* cmodel;
+typedef const __attribute__((address_space(4))) double* cdoubles;
+
 struct LaunchGeom {          // host-computed K2 work split (see plan_k2 in mwrt.hip)
   int nseg;                  // level segments per (freq, angle) pair
   int seglen;                // layers per segment
@@ -35,7 +45,7 @@ struct LaunchGeom {          // host-computed K2 work split (see plan_k2 in mwrt
 #define MWRT_EXACT_DIV 0
 #endif
 
-// x / d with v_rcp_f64 + two Newton steps (error ~1 ulp; parity bar is 1e-6 K, budget 0.01 K).
+// x / d with v_rcp_f64 + two Newton steps (~1.5 ulp; parity bar is 1e-6 K, budget 0.01 K).
 __device__ __forceinline__ double fdiv(double x, double d) {
 #if MWRT_EXACT_DIV
   return x / d;
@@ -45,9 +55,18 @@ __device__ __forceinline__ double fdiv(double x, double d) {
   r = __builtin_fma(r, e, r);
   e = __builtin_fma(-d, r, 1.0);
   r = __builtin_fma(r, e, r);
-  double q = x * r;
-  // one residual correction makes q correctly rounded in all but pathological cases
-  return __builtin_fma(__builtin_fma(-d, q, x), r, q);
+  return x * r;
+#endif
+}
+
+// inner-loop variant: one Newton step (v_rcp_f64 is good to ~2^-23, so ~2^-46 ~ 1.4e-14 relative)
+__device__ __forceinline__ double fdiv1(double x, double d) {
+#if MWRT_EXACT_DIV
+  return x / d;
+#else
+  double r = __builtin_amdgcn_rcp(d);
+  r = __builtin_fma(r, __builtin_fma(-d, r, 1.0), r);
+  return x * r;
 #endif
 }
 
@@ -135,10 +154,48 @@ __device__ __forceinline__ LevelState level_state(double p_hpa, double tk, doubl
 
 // ---------------------------------------------------------------------------------------------
 // K1a: H2O lines + continuum for NFC uniform frequencies (H2OAbsModel.h2o_absorption [EXT])
+//
+// Per line the two Lorentz terms share ONE reciprocal:
+//   s*[m1*(w/(D1) - base) + m2*(w/(D2) - base)] = (s w) (m1 D2 + m2 D1)/(D1 D2) - (m1+m2)(s base)
+// with m = 1.0/0.0 for the 750-GHz cutoff.  The speed-dependent 22/183-GHz resonant term is
+// evaluated in a second, short loop over the SD lines only (keeps the hot loop branch-free).
 // ---------------------------------------------------------------------------------------------
+struct H2OLine {          // per-(level, line) quantities, frequency independent
+  double c1;              // line centre + pressure shift
+  double w0, wsq;         // half width, squared
+  double sw;              // S/fl^2 * w0
+  double sbase;           // S/fl^2 * base
+  double s;               // S/fl^2
+  double base;
+};
+
+__device__ __forceinline__ H2OLine h2o_line(cmodel M, int k, double pda, double pvap, double ti, double tiln,
+                                            double ti2, bool shifted) {
+  H2OLine q;
+  const double fl = M->h2o_fl[k];
+  q.w0 = M->h2o_w0[k] * pda * exp(M->h2o_x[k] * tiln) + M->h2o_w0s[k] * pvap * exp(M->h2o_xs[k] * tiln);
+  double shift = 0.0;
+  if (shifted) {
+    // exponents / ln-T coefficients that are zero in the table cost nothing (uniform branches)
+    const double xh = M->h2o_xh[k], xhs = M->h2o_xhs[k], aa = M->h2o_aair[k], as = M->h2o_aself[k];
+    double sf = M->h2o_sh[k] * pda, ss = M->h2o_shs[k] * pvap;
+    if (aa != 0.0) sf *= (1.0 - aa * tiln);
+    if (as != 0.0) ss *= (1.0 - as * tiln);
+    if (xh != 0.0) sf *= exp(xh * tiln);
+    if (xhs != 0.0) ss *= exp(xhs * tiln);
+    shift = sf + ss;
+  }
+  q.wsq = q.w0 * q.w0;
+  q.s = fdiv(M->h2o_s1[k] * ti2 * exp(M->h2o_b2[k] * (1.0 - ti)), fl * fl);   // (f/fl)^2: f^2 applied at the end
+  q.base = fdiv(q.w0, 562500.0 + q.wsq);
+  q.c1 = fl + shift;
+  q.sw = q.s * q.w0;
+  q.sbase = q.s * q.base;
+  return q;
+}
+
 template <int NFC>
-__device__ __forceinline__ void h2o_absorb(const mwrt_model_desc* __restrict__ M, const LevelState& L,
-                                           const double* __restrict__ fq /*uniform, NFC valid*/,
+__device__ __forceinline__ void h2o_absorb(cmodel M, const LevelState& L, const double (&fq)[NFC],
                                            double (&awet)[NFC]) {
   const double t = L.t;
   const double pvap = fdiv(L.rho * t, M->h2o_pvap_div);
@@ -155,45 +212,55 @@ __device__ __forceinline__ void h2o_absorb(const mwrt_model_desc* __restrict__ M
   for (int j = 0; j < NFC; ++j) sum[j] = 0.0;
 
   const int nl = M->n_h2o;
+  int n_sd = 0;
   for (int k = 0; k < nl; ++k) {
-    const double fl = M->h2o_fl[k];
-    const double w0 = M->h2o_w0[k] * pda * exp(M->h2o_x[k] * tiln) + M->h2o_w0s[k] * pvap * exp(M->h2o_xs[k] * tiln);
-    double shift = 0.0;
-    if (shifted) {
-      shift = M->h2o_sh[k] * pda * (1.0 - M->h2o_aair[k] * tiln) * exp(M->h2o_xh[k] * tiln)
-            + M->h2o_shs[k] * pvap * (1.0 - M->h2o_aself[k] * tiln) * exp(M->h2o_xhs[k] * tiln);
-    }
-    const double wsq = w0 * w0;
-    // S * (f/fl)^2: the f^2 is applied once at the end
-    const double s = fdiv(M->h2o_s1[k] * ti2 * exp(M->h2o_b2[k] * (1.0 - ti)), fl * fl);
-    const double base = fdiv(w0, 562500.0 + wsq);
-    const double c1 = fl + shift;
-    const bool sd_line = M->h2o_w2[k] > 0.0;      // wave-uniform
-    double w2 = 0.0, delta2 = 0.0;
-    if (sd_line) {
-      w2 = M->h2o_w2[k] * pda * exp(M->h2o_xw2[k] * tiln) + M->h2o_w2s[k] * pvap * exp(M->h2o_xw2s[k] * tiln);
-      delta2 = M->h2o_d2[k] * pda + M->h2o_d2s[k] * pvap;
-    }
+    const H2OLine q = h2o_line(M, k, pda, pvap, ti, tiln, ti2, shifted);
+    const bool sd_line = M->h2o_w2[k] > 0.0;                  // wave-uniform
+    n_sd += sd_line ? 1 : 0;
+    const double sdlim = sd_line ? 10.0 * q.w0 : -1.0;        // |d1| < sdlim -> handled by the SD loop
 #pragma unroll
     for (int j = 0; j < NFC; ++j) {
       const double f = fq[j];
-      const double d1 = f - c1;
-      const double d2 = f + c1;
-      double res = 0.0;
-      double r1 = (fabs(d1) < 750.0) ? (fdiv(w0, d1 * d1 + wsq) - base) : 0.0;
-      if (sd_line && w2 > 0.0 && fabs(d1) < 10.0 * w0) {
-        // speed-dependent resonant shape factor (ABH2O_SD): Xc = (w0-1.5w2 + i(d1+1.5 delta2)) / (w2 - i delta2)
-        cplx den2 = {w2, -delta2};
-        cplx xc = cdiv(cplx{w0 - 1.5 * w2, d1 + 1.5 * delta2}, den2);
-        cplx xrt = csqrt_principal(xc);
-        cplx w = dcerror_upper(-xrt.im, xrt.re);
-        cplx pxw = cmul(cplx{1.77245385090551603 * xrt.re, 1.77245385090551603 * xrt.im}, w);
-        cplx sd = cdiv(cplx{2.0 * (1.0 - pxw.re), -2.0 * pxw.im}, den2);
-        r1 = sd.re - base;
+      const double d1 = f - q.c1;
+      const double d2 = f + q.c1;
+      const double D1 = __builtin_fma(d1, d1, q.wsq);
+      const double D2 = __builtin_fma(d2, d2, q.wsq);
+      const double a1 = fabs(d1);
+      const double m1 = (a1 < 750.0 && !(a1 < sdlim)) ? 1.0 : 0.0;
+      const double m2 = (fabs(d2) < 750.0) ? 1.0 : 0.0;
+      const double num = __builtin_fma(m2, D1, m1 * D2);
+      const double r = fdiv1(num, D1 * D2);
+      sum[j] = __builtin_fma(r, q.sw, sum[j]);
+      sum[j] = __builtin_fma(-(m1 + m2), q.sbase, sum[j]);
+    }
+  }
+  if (n_sd > 0) {
+    // speed-dependent resonant shape factor (ABH2O_SD) for the lines that carry W2 > 0:
+    //   Xc = (w0 - 1.5 w2 + i (d1 + 1.5 delta2)) / (w2 - i delta2);  SD = 2 (1 - sqrt(pi) Xrt w(i Xrt)) / (w2 - i delta2)
+    for (int k = 0; k < nl; ++k) {
+      if (!(M->h2o_w2[k] > 0.0)) continue;
+      const H2OLine q = h2o_line(M, k, pda, pvap, ti, tiln, ti2, shifted);
+      const double w2 = M->h2o_w2[k] * pda * exp(M->h2o_xw2[k] * tiln) + M->h2o_w2s[k] * pvap * exp(M->h2o_xw2s[k] * tiln);
+      const double delta2 = M->h2o_d2[k] * pda + M->h2o_d2s[k] * pvap;
+      const cplx den2 = {w2, -delta2};
+#pragma unroll
+      for (int j = 0; j < NFC; ++j) {
+        const double d1 = fq[j] - q.c1;
+        if (fabs(d1) < 10.0 * q.w0) {
+          double r1;
+          if (w2 > 0.0) {
+            cplx xc = cdiv(cplx{q.w0 - 1.5 * w2, d1 + 1.5 * delta2}, den2);
+            cplx xrt = csqrt_principal(xc);
+            cplx w = dcerror_upper(-xrt.im, xrt.re);
+            cplx pxw = cmul(cplx{1.77245385090551603 * xrt.re, 1.77245385090551603 * xrt.im}, w);
+            cplx sd = cdiv(cplx{2.0 * (1.0 - pxw.re), -2.0 * pxw.im}, den2);
+            r1 = sd.re - q.base;
+          } else {                                              // width2 == 0: plain Lorentz + cutoff
+            r1 = (fabs(d1) < 750.0) ? (fdiv(q.w0, __builtin_fma(d1, d1, q.wsq)) - q.base) : 0.0;
+          }
+          sum[j] = __builtin_fma(q.s, r1, sum[j]);
+        }
       }
-      res += r1;
-      if (fabs(d2) < 750.0) res += fdiv(w0, d2 * d2 + wsq) - base;
-      sum[j] = __builtin_fma(s, res, sum[j]);
     }
   }
   const bool dry = !(L.rho > 0.0);
@@ -206,10 +273,11 @@ __device__ __forceinline__ void h2o_absorb(const mwrt_model_desc* __restrict__ M
 
 // ---------------------------------------------------------------------------------------------
 // K1b: O2 lines + non-resonant + N2 continuum (O2AbsModel.o2_absorption / N2AbsModel [EXT])
+//   S (f/F)^2 [ (w g + d1 Y)/D1 + (w g - d2 Y)/D2 ]  with one reciprocal per line and frequency
 // ---------------------------------------------------------------------------------------------
 template <int NFC>
-__device__ __forceinline__ void dry_absorb(const mwrt_model_desc* __restrict__ M, const LevelState& L,
-                                           const double* __restrict__ fq, double (&adry)[NFC]) {
+__device__ __forceinline__ void dry_absorb(cmodel M, const LevelState& L, const double (&fq)[NFC],
+                                           double (&adry)[NFC]) {
   const double temp = L.t;
   const double pres = L.p;
   const double th = fdiv(300.0, temp);
@@ -239,7 +307,7 @@ __device__ __forceinline__ void dry_absorb(const mwrt_model_desc* __restrict__ M
       gfac = 1.0 + pe2 * (M->o2_g0[k] + M->o2_g1[k] * th1);
     }
     const double df = M->o2_w300[k] * ((k == 0 && M->o2_line1_dens) ? dens : den);
-    const double str = fdiv(M->o2_s300[k] * exp(-M->o2_be[k] * th1), fk * fk);   // * f^2 at the end
+    const double str = M->o2_s300[k] * exp(-M->o2_be[k] * th1) * M->o2_rf2[k];   // * f^2 at the end
     const double c1 = fk + dnu;
     const double df2 = df * df;
     const double a = str * df * gfac;
@@ -253,8 +321,7 @@ __device__ __forceinline__ void dry_absorb(const mwrt_model_desc* __restrict__ M
       const double D2 = __builtin_fma(d2, d2, df2);
       const double n1 = __builtin_fma(d1, bb, a);
       const double n2 = __builtin_fma(-d2, bb, a);
-      // n1/D1 + n2/D2 with a single reciprocal
-      sum[j] += fdiv(__builtin_fma(n1, D2, n2 * D1), D1 * D2);
+      sum[j] += fdiv1(__builtin_fma(n1, D2, n2 * D1), D1 * D2);
     }
   }
   const double scale = M->o2_coef * presda * th * th * th;
@@ -287,7 +354,7 @@ __device__ __forceinline__ double layer_value(double x1, double x0, bool& neg) {
 // fused kernel: profile in -> TB out
 // ---------------------------------------------------------------------------------------------
 struct FusedArgs {
-  const mwrt_model_desc* M;
+  const ModelFlat* M;
   const double* z; const double* p; const double* t; const double* rh;   // [nprof][nlev]
   const double* frq;       // [nf] device
   const double* airmass;   // [nang] device: 1/sin(elev)
@@ -309,7 +376,9 @@ k_tb_fused(const FusedArgs A) {
   const int jbase = blockIdx.y * NFC;
   const int nfc = min(NFC, A.nf - jbase);
   const int nlev = A.nlev, nang = A.nang, ld = A.g.ldrow;
-  const mwrt_model_desc* __restrict__ M = A.M;
+  const cmodel M = (cmodel)A.M;
+  const cdoubles cfrq = (cdoubles)A.frq;
+  const cdoubles cam = (cdoubles)A.airmass;
 
   double* tau = lds;                        // [NFC][ld]  zenith layer optical depth (wet+dry)
   double* bof = lds + (size_t)NFC * ld;     // [NFC][ld]  Planck function B(T_i, f_j)
@@ -320,7 +389,7 @@ k_tb_fused(const FusedArgs A) {
   // uniform frequency chunk; lanes beyond nfc reuse the last valid one (results discarded)
   double fq[NFC];
 #pragma unroll
-  for (int j = 0; j < NFC; ++j) fq[j] = A.frq[jbase + min(j, nfc - 1)];
+  for (int j = 0; j < NFC; ++j) fq[j] = cfrq[jbase + min(j, nfc - 1)];
 
   if (tid == 0) s_flag = 0;
   __syncthreads();
@@ -427,7 +496,7 @@ k_tb_fused(const FusedArgs A) {
     const int pr = it - seg * npairs;
     const int j = pr / nang;
     const int a = pr - j * nang;
-    const double am = A.airmass[a];
+    const double am = cam[a];
     const int lo = 1 + seg * seglen;
     const int hi = min(lo + seglen, nlev);
     const double* tj = tau + j * ld;
@@ -457,7 +526,7 @@ k_tb_fused(const FusedArgs A) {
       T *= q[1];
       S += q[2];
     }
-    const double hvk = A.frq[jbase + j] * hk;
+    const double hvk = cfrq[jbase + j] * hk;
     double boftotl, boftmr;
     if (S < TAUMAX) {
       const double ex = exp(-S);
@@ -472,7 +541,7 @@ k_tb_fused(const FusedArgs A) {
     if (A.tbatm) A.tbatm[o] = fdiv(hvk, log(1.0 + fdiv(1.0, B)));
     if (A.tmr) A.tmr[o] = fdiv(hvk, log(1.0 + fdiv(1.0, boftmr)));
     if (want_tau) {
-      const double am = A.airmass[a];
+      const double am = cam[a];
       double sw = 0.0, sd = 0.0;
 #pragma unroll
       for (int jj = 0; jj < NFC; ++jj) if (jj == j) { sw = swet[jj]; sd = sdry[jj]; }
@@ -486,7 +555,7 @@ k_tb_fused(const FusedArgs A) {
 // K1 alone: awet / adry [nprof][nf][nlev] (RTEquation.clearsky_absorption [EXT])
 // ---------------------------------------------------------------------------------------------
 struct AbsorbArgs {
-  const mwrt_model_desc* M;
+  const ModelFlat* M;
   const double* p; const double* t; const double* rh;
   const double* frq;
   double* awet; double* adry;
@@ -500,17 +569,19 @@ k_absorb(const AbsorbArgs A) {
   const int64_t prof = blockIdx.x;
   const int jbase = blockIdx.y * NFC;
   const int nfc = min(NFC, A.nf - jbase);
+  const cmodel M = (cmodel)A.M;
+  const cdoubles cfrq = (cdoubles)A.frq;
   double fq[NFC];
 #pragma unroll
-  for (int j = 0; j < NFC; ++j) fq[j] = A.frq[jbase + min(j, nfc - 1)];
+  for (int j = 0; j < NFC; ++j) fq[j] = cfrq[jbase + min(j, nfc - 1)];
   const bool active = tid < A.nlev;
   const int64_t off = prof * A.nlev + (active ? tid : 0);
   const double pi = A.p[off], ti = A.t[off], rhi = A.rh[off];
   double awet[NFC], adry[NFC];
   const double e = goff_gratch_e(ti, rhi);
   const LevelState L = level_state(pi, ti, e);
-  h2o_absorb<NFC>(A.M, L, fq, awet);
-  dry_absorb<NFC>(A.M, L, fq, adry);
+  h2o_absorb<NFC>(M, L, fq, awet);
+  dry_absorb<NFC>(M, L, fq, adry);
   if (active) {
 #pragma unroll
     for (int j = 0; j < NFC; ++j) {
