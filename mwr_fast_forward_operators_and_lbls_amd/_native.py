@@ -94,7 +94,7 @@ def load_library(path: Optional[str] = None) -> ctypes.CDLL:
     with _lib_lock:
         if _lib is not None and path is None:
             return _lib
-        p = path or LIB_PATH
+        p = path or os.environ.get("MWRT_LIB") or LIB_PATH      # MWRT_LIB: diagnostic builds only
         if not os.path.exists(p):
             raise NativeLibraryMissing(
                 f"{p} not built: run `python -c 'import __graft_entry__ as g; g.build()'` "

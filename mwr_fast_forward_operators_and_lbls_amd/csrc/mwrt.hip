@@ -88,8 +88,13 @@ LaunchGeom plan_k2(int nlev, int npairs, int threads) {
   return g;
 }
 
+// rows kept in LDS per K2 pass for a chunk width
+int nfk_of(int nfc) { return nfc == 14 ? 7 : 8; }
+
 size_t fused_lds_bytes(int nfc, const LaunchGeom& g, int nang, int threads) {
-  return sizeof(double) * ((size_t)2 * nfc * g.ldrow + (size_t)3 * nfc * nang * g.nseg + threads / WAVE + 2);
+  const int nfk = nfk_of(nfc);
+  return sizeof(double) * ((size_t)2 * nfk * g.ldrow + (size_t)3 * nfk * nang * g.nseg + 16 +
+                           (size_t)(threads / WAVE) * 2 * nfc);
 }
 
 // K2 split for a chunk width, shrunk until the workgroup's LDS fits; false if it cannot
@@ -138,13 +143,17 @@ int launch_fused(mwrt_context* c, FusedArgs a, int64_t nprof, hipStream_t st) {
   if (!plan_fused(c, NFC, a.nlev, a.nf, a.nang, &a.g, &lds))
     return fail(MWRT_ERR_UNSUPPORTED, "LDS budget exceeded (nlev x nang too large)");
   dim3 grid((unsigned)nprof, (unsigned)nchunks), block(threads);
+  // valid[] = 1 is written by the kernel itself when one workgroup owns the profile; with several
+  // frequency chunks per profile the flags are preset here and the kernel only lowers/raises them
+  a.write_valid = nchunks == 1;
+  if (!a.write_valid) HIP_TRY(hipMemsetAsync(a.valid, 1, (size_t)nprof, st));
   timing_begin(c, st);
   if (threads <= 256) {
-    auto k = k_tb_fused<NFC, 256>;
+    auto k = k_tb_fused<NFC, (NFC == 14 ? 7 : 8), 256>;
     HIP_TRY(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(k, grid, block, lds, st, a);
   } else {
-    auto k = k_tb_fused<NFC, 1024>;
+    auto k = k_tb_fused<NFC, (NFC == 14 ? 7 : 8), 1024>;
     HIP_TRY(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(k, grid, block, lds, st, a);
   }
@@ -168,7 +177,7 @@ int launch_absorb(mwrt_context* c, AbsorbArgs a, int64_t nprof, hipStream_t st) 
 
 bool plan_fused(const mwrt_context* c, int nfc, int nlev, int nf, int nang, LaunchGeom* g, size_t* lds) {
   const int threads = ((nlev + WAVE - 1) / WAVE) * WAVE;
-  *g = plan_k2(nlev, std::min(nfc, nf) * nang, threads);
+  *g = plan_k2(nlev, std::min(nfk_of(nfc), nf) * nang, threads);
   *lds = fused_lds_bytes(nfc, *g, nang, threads);
   while (*lds > (size_t)c->lds_max && g->nseg > 1) {     // shrink the partials if LDS is short
     g->nseg = (g->nseg + 1) / 2;
@@ -296,7 +305,6 @@ int mwrt_tb_batch_device(mwrt_context* c, const mwrt_model* m, int64_t nprof, in
   for (int a = 0; a < nang; ++a) am[a] = 1.0 / std::sin(elev[a] * M_PI / 180.0);   // plane-parallel air mass
   rc = upload_small(c, c->d_frq, c->h_frq, frq, nf, st); if (rc) return rc;
   rc = upload_small(c, c->d_am, c->h_am, am.data(), nang, st); if (rc) return rc;
-  HIP_TRY(hipMemsetAsync(d_valid, 1, (size_t)nprof, st));
 
   FusedArgs a{};
   a.M = m->d_desc; a.z = d_z; a.p = d_p; a.t = d_t; a.rh = d_rh;

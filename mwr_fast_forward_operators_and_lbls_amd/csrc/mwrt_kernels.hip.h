@@ -44,6 +44,11 @@ struct LaunchGeom {          // host-computed K2 work split (see plan_k2 in mwrt
 #ifndef MWRT_EXACT_DIV
 #define MWRT_EXACT_DIV 0
 #endif
+// timing-only ablation builds (tools/ablate.sh): bit 1 skips the O2 line loop, 2 the H2O Lorentz
+// loop, 4 the speed-dependent loop, 8 the K2 integration.  Always 0 in the shipped library.
+#ifndef MWRT_ABLATE
+#define MWRT_ABLATE 0
+#endif
 
 // x / d with v_rcp_f64 + two Newton steps (~1.5 ulp; parity bar is 1e-6 K, budget 0.01 K).
 __device__ __forceinline__ double fdiv(double x, double d) {
@@ -69,6 +74,12 @@ __device__ __forceinline__ double fdiv1(double x, double d) {
   return x * r;
 #endif
 }
+
+// Frequencies are wave-uniform.  Held in SGPRs, {f, f^2} x 14 is 56 scalar registers and the
+// allocator spills them into VGPR lanes (v_readlane per use).  They live in LDS instead and are
+// re-read by broadcast each line iteration; the fence stops the compiler hoisting the reads
+// back into (vector) registers across the line loop.
+#define LDS_RELOAD_FENCE() asm volatile("" ::: "memory")
 
 struct cplx { double re, im; };
 __device__ __forceinline__ cplx cmul(cplx a, cplx b) { return {a.re * b.re - a.im * b.im, a.re * b.im + a.im * b.re}; }
@@ -195,7 +206,7 @@ __device__ __forceinline__ H2OLine h2o_line(cmodel M, int k, double pda, double 
 }
 
 template <int NFC>
-__device__ __forceinline__ void h2o_absorb(cmodel M, const LevelState& L, const double (&fq)[NFC],
+__device__ __forceinline__ void h2o_absorb(cmodel M, const LevelState& L, const double* sfq /*LDS: {f, f^2} per slot*/,
                                            double (&awet)[NFC]) {
   const double t = L.t;
   const double pvap = fdiv(L.rho * t, M->h2o_pvap_div);
@@ -213,28 +224,73 @@ __device__ __forceinline__ void h2o_absorb(cmodel M, const LevelState& L, const 
 
   const int nl = M->n_h2o;
   int n_sd = 0;
-  for (int k = 0; k < nl; ++k) {
+  // The 750-GHz cutoff of each Lorentz term depends on the lane only through the (tiny) pressure
+  // shift.  Per line the wave votes once whether every lane agrees for EVERY frequency of the
+  // chunk (tested at the chunk's extreme frequencies); if so the masks drop out of the hot loop:
+  //   both terms in   : s w (D1 + D2)/(D1 D2) - 2 s base     (the usual case)
+  //   resonant only   : s w / D1 - s base                     (e.g. 752 GHz seen from 22 GHz)
+  //   none            : line skipped                          (e.g. 916 GHz)
+  // anything else (and the speed-dependent lines) takes the masked form.
+  const double fmin = sfq[2 * NFC], fmax = sfq[2 * NFC + 1];
+  double bsum = 0.0;                                          // sum of (count * s * base), frequency independent
+  for (int k = 0; k < ((MWRT_ABLATE & 2) ? 0 : nl); ++k) {
     const H2OLine q = h2o_line(M, k, pda, pvap, ti, tiln, ti2, shifted);
     const bool sd_line = M->h2o_w2[k] > 0.0;                  // wave-uniform
     n_sd += sd_line ? 1 : 0;
-    const double sdlim = sd_line ? 10.0 * q.w0 : -1.0;        // |d1| < sdlim -> handled by the SD loop
+    const bool d1_in = (q.c1 - fmin < 750.0) && (fmax - q.c1 < 750.0) && (q.c1 - fmin > -750.0);
+    const bool d1_out = (q.c1 - fmax >= 750.0) || (fmin - q.c1 >= 750.0);
+    const bool d2_in = fmax + q.c1 < 750.0 && fmin + q.c1 > -750.0;
+    const bool d2_out = fmin + q.c1 >= 750.0;
+    const bool all_both = !sd_line && __all(d1_in && d2_in);
+    const bool all_res = !sd_line && __all(d1_in && d2_out);
+    const bool all_none = !sd_line && __all(d1_out && d2_out);
+    LDS_RELOAD_FENCE();
+    if (all_both) {
+      bsum = __builtin_fma(2.0, q.sbase, bsum);
 #pragma unroll
-    for (int j = 0; j < NFC; ++j) {
-      const double f = fq[j];
-      const double d1 = f - q.c1;
-      const double d2 = f + q.c1;
-      const double D1 = __builtin_fma(d1, d1, q.wsq);
-      const double D2 = __builtin_fma(d2, d2, q.wsq);
-      const double a1 = fabs(d1);
-      const double m1 = (a1 < 750.0 && !(a1 < sdlim)) ? 1.0 : 0.0;
-      const double m2 = (fabs(d2) < 750.0) ? 1.0 : 0.0;
-      const double num = __builtin_fma(m2, D1, m1 * D2);
-      const double r = fdiv1(num, D1 * D2);
-      sum[j] = __builtin_fma(r, q.sw, sum[j]);
-      sum[j] = __builtin_fma(-(m1 + m2), q.sbase, sum[j]);
+      for (int j = 0; j < NFC; ++j) {
+        const double f = sfq[2 * j];
+        const double d1 = f - q.c1;
+        const double d2 = f + q.c1;
+        const double D1 = __builtin_fma(d1, d1, q.wsq);
+        const double D2 = __builtin_fma(d2, d2, q.wsq);
+        const double den12 = D1 * D2;
+        double r = __builtin_amdgcn_rcp(den12);
+        r = __builtin_fma(r, __builtin_fma(-den12, r, 1.0), r);
+        sum[j] = __builtin_fma((D1 + D2) * r, q.sw, sum[j]);
+      }
+    } else if (all_res) {
+      bsum += q.sbase;
+#pragma unroll
+      for (int j = 0; j < NFC; ++j) {
+        const double d1 = sfq[2 * j] - q.c1;
+        const double D1 = __builtin_fma(d1, d1, q.wsq);
+        double r = __builtin_amdgcn_rcp(D1);
+        r = __builtin_fma(r, __builtin_fma(-D1, r, 1.0), r);
+        sum[j] = __builtin_fma(r, q.sw, sum[j]);
+      }
+    } else if (!all_none) {
+      const double sdlim = sd_line ? 10.0 * q.w0 : -1.0;      // |d1| < sdlim -> handled by the SD loop
+#pragma unroll
+      for (int j = 0; j < NFC; ++j) {
+        const double f = sfq[2 * j];
+        const double d1 = f - q.c1;
+        const double d2 = f + q.c1;
+        const double D1 = __builtin_fma(d1, d1, q.wsq);
+        const double D2 = __builtin_fma(d2, d2, q.wsq);
+        const double a1 = fabs(d1);
+        const double m1 = (a1 < 750.0 && !(a1 < sdlim)) ? 1.0 : 0.0;
+        const double m2 = (fabs(d2) < 750.0) ? 1.0 : 0.0;
+        const double num = __builtin_fma(m2, D1, m1 * D2);
+        const double r = fdiv1(num, D1 * D2);
+        sum[j] = __builtin_fma(r, q.sw, sum[j]);
+        sum[j] = __builtin_fma(-(m1 + m2), q.sbase, sum[j]);
+      }
     }
   }
-  if (n_sd > 0) {
+#pragma unroll
+  for (int j = 0; j < NFC; ++j) sum[j] -= bsum;
+  if (n_sd > 0 && !(MWRT_ABLATE & 4)) {
     // speed-dependent resonant shape factor (ABH2O_SD) for the lines that carry W2 > 0:
     //   Xc = (w0 - 1.5 w2 + i (d1 + 1.5 delta2)) / (w2 - i delta2);  SD = 2 (1 - sqrt(pi) Xrt w(i Xrt)) / (w2 - i delta2)
     for (int k = 0; k < nl; ++k) {
@@ -245,7 +301,7 @@ __device__ __forceinline__ void h2o_absorb(cmodel M, const LevelState& L, const 
       const cplx den2 = {w2, -delta2};
 #pragma unroll
       for (int j = 0; j < NFC; ++j) {
-        const double d1 = fq[j] - q.c1;
+        const double d1 = sfq[2 * j] - q.c1;
         if (fabs(d1) < 10.0 * q.w0) {
           double r1;
           if (w2 > 0.0) {
@@ -266,7 +322,7 @@ __device__ __forceinline__ void h2o_absorb(cmodel M, const LevelState& L, const 
   const bool dry = !(L.rho > 0.0);
 #pragma unroll
   for (int j = 0; j < NFC; ++j) {
-    const double f2 = fq[j] * fq[j];
+    const double f2 = sfq[2 * j + 1];
     awet[j] = dry ? 0.0 : (3.183e-05 * den * sum[j] + con0) * f2;
   }
 }
@@ -276,7 +332,7 @@ __device__ __forceinline__ void h2o_absorb(cmodel M, const LevelState& L, const 
 //   S (f/F)^2 [ (w g + d1 Y)/D1 + (w g - d2 Y)/D2 ]  with one reciprocal per line and frequency
 // ---------------------------------------------------------------------------------------------
 template <int NFC>
-__device__ __forceinline__ void dry_absorb(cmodel M, const LevelState& L, const double (&fq)[NFC],
+__device__ __forceinline__ void dry_absorb(cmodel M, const LevelState& L, const double* sfq /*LDS: {f, f^2} per slot*/,
                                            double (&adry)[NFC]) {
   const double temp = L.t;
   const double pres = L.p;
@@ -297,7 +353,12 @@ __device__ __forceinline__ void dry_absorb(cmodel M, const LevelState& L, const 
 #pragma unroll
   for (int j = 0; j < NFC; ++j) sum[j] = 0.0;
 
-  const int nl = M->n_o2;
+  // With d1 = f - c, d2 = f + c, D = d^2 + w^2, n1 = a + d1 b, n2 = a - d2 b the two terms of a line
+  // share one reciprocal and the numerator collapses to a polynomial in f^2:
+  //   n1/D1 + n2/D2 = (f^2 P + Q) / (D1 D2),  P = 2 (a + c b),  Q = 2 (c^2 + w^2)(a - c b)
+  // (D1, D2 are still formed from d1, d2 directly: no cancellation next to a line centre).
+  const int nl = (MWRT_ABLATE & 1) ? 0 : M->n_o2;
+  double be_prev = -1.0, ebe = 1.0;
   for (int k = 0; k < nl; ++k) {
     const double fk = M->o2_f[k];
     const double y = ymul * (M->o2_y0[k] + M->o2_y1[k] * th1);
@@ -307,21 +368,27 @@ __device__ __forceinline__ void dry_absorb(cmodel M, const LevelState& L, const 
       gfac = 1.0 + pe2 * (M->o2_g0[k] + M->o2_g1[k] * th1);
     }
     const double df = M->o2_w300[k] * ((k == 0 && M->o2_line1_dens) ? dens : den);
-    const double str = M->o2_s300[k] * exp(-M->o2_be[k] * th1) * M->o2_rf2[k];   // * f^2 at the end
+    const double be = M->o2_be[k];
+    if (be != be_prev) { ebe = exp(-be * th1); be_prev = be; }     // N- / N+ partners share BE (uniform branch)
+    const double str = M->o2_s300[k] * ebe * M->o2_rf2[k];           // * f^2 at the end
     const double c1 = fk + dnu;
     const double df2 = df * df;
     const double a = str * df * gfac;
-    const double bb = str * y;
+    const double cb = c1 * (str * y);
+    const double P = 2.0 * (a + cb);
+    const double Q = 2.0 * __builtin_fma(c1, c1, df2) * (a - cb);
+    LDS_RELOAD_FENCE();
 #pragma unroll
     for (int j = 0; j < NFC; ++j) {
-      const double f = fq[j];
+      const double f = sfq[2 * j], f2 = sfq[2 * j + 1];
       const double d1 = f - c1;
       const double d2 = f + c1;
       const double D1 = __builtin_fma(d1, d1, df2);
       const double D2 = __builtin_fma(d2, d2, df2);
-      const double n1 = __builtin_fma(d1, bb, a);
-      const double n2 = __builtin_fma(-d2, bb, a);
-      sum[j] += fdiv1(__builtin_fma(n1, D2, n2 * D1), D1 * D2);
+      const double den12 = D1 * D2;
+      double r = __builtin_amdgcn_rcp(den12);
+      r = __builtin_fma(r, __builtin_fma(-den12, r, 1.0), r);
+      sum[j] = __builtin_fma(__builtin_fma(f2, P, Q), r, sum[j]);
     }
   }
   const double scale = M->o2_coef * presda * th * th * th;
@@ -330,8 +397,8 @@ __device__ __forceinline__ void dry_absorb(cmodel M, const LevelState& L, const 
   const double n2c = M->n2_n * M->n2_l * pn2 * pn2 * exp(M->n2_m * lnth);
 #pragma unroll
   for (int j = 0; j < NFC; ++j) {
-    const double f = fq[j];
-    const double f2 = f * f;
+    const double f = sfq[2 * j];
+    const double f2 = sfq[2 * j + 1];
     const double nonres = fdiv(M->o2_nonres * f2 * dfnr, th * (f2 + dfnr * dfnr));
     double o2 = scale * __builtin_fma(sum[j], f2, nonres);
     o2 = fmax(o2, 0.0);
@@ -363,15 +430,42 @@ struct FusedArgs {
   double* tbatm; double* tmr; double* tauwet; double* taudry;   // optional [nprof][nang][nf]
   double* taulay;          // optional [nprof][nf][nlev]
   int nlev, nf, nang;
+  int write_valid;         // 1: this launch has one workgroup per profile and sets valid = 1 itself
   LaunchGeom g;
 };
 
-template <int NFC, int MAXT>
+// NaN / negative-absorption exit: every output of this (profile, chunk) becomes NaN
+__device__ __forceinline__ void blank_outputs(const FusedArgs& A, int64_t prof, int jbase, int nfc, int tid, int nthreads) {
+  const double qnan = __builtin_nan("");
+  const int nang = A.nang, nlev = A.nlev;
+  for (int it = tid; it < nfc * nang; it += nthreads) {
+    const int j = it / nang, a = it % nang;
+    const int64_t o = (prof * nang + a) * A.nf + jbase + j;
+    A.tb[o] = qnan;
+    if (A.tbatm) A.tbatm[o] = qnan;
+    if (A.tmr) A.tmr[o] = qnan;
+    if (A.tauwet) A.tauwet[o] = qnan;
+    if (A.taudry) A.taudry[o] = qnan;
+  }
+  if (A.taulay) for (int it = tid; it < nfc * nlev; it += nthreads)
+    A.taulay[(prof * A.nf + jbase + it / nlev) * nlev + it % nlev] = qnan;
+}
+
+// NFC = frequencies per workgroup (accumulators in registers during K1);
+// NFK = frequencies per K2 pass (rows of tau / B kept in LDS at a time): NFC = NPASS * NFK.
+// Keeping only NFK rows resident holds the workgroup under 40 KB of LDS, so FOUR 192-thread
+// workgroups (12 waves = 3 per SIMD) fit a CU and a 1000-profile batch is one resident round.
+template <int NFC, int NFK, int MAXT>
 __global__ void __launch_bounds__(MAXT)
 k_tb_fused(const FusedArgs A) {
+  static_assert(NFC % NFK == 0, "NFC must be a multiple of NFK");
+  constexpr int NPASS = NFC / NFK;
   extern __shared__ double lds[];
   const int tid = threadIdx.x;
+  const int lane = tid & (WAVE - 1);
+  const int wave = tid / WAVE;
   const int nthreads = blockDim.x;
+  const int nwaves = nthreads / WAVE;
   const int64_t prof = blockIdx.x;
   const int jbase = blockIdx.y * NFC;
   const int nfc = min(NFC, A.nf - jbase);
@@ -380,18 +474,22 @@ k_tb_fused(const FusedArgs A) {
   const cdoubles cfrq = (cdoubles)A.frq;
   const cdoubles cam = (cdoubles)A.airmass;
 
-  double* tau = lds;                        // [NFC][ld]  zenith layer optical depth (wet+dry)
-  double* bof = lds + (size_t)NFC * ld;     // [NFC][ld]  Planck function B(T_i, f_j)
-  double* part = bof + (size_t)NFC * ld;    // [items][3] segment partials (B, T, sum tau)
-  double* scratch = part + (size_t)3 * NFC * nang * A.g.nseg;  // [nwaves]
+  double* tau = lds;                                     // [NFK][ld] zenith layer optical depth (wet+dry)
+  double* bof = tau + (size_t)NFK * ld;                  // [NFK][ld] Planck function B(T_i, f_j)
+  double* part = bof + (size_t)NFK * ld;                 // [NFK*nang*nseg][3] segment partials (B, T, sum tau)
+  double* scratch = part + (size_t)3 * NFK * nang * A.g.nseg;   // [16] block_sum scratch
+  double* edge = scratch + 16;                           // [nwaves][2*NFC] last lane of each wave
   __shared__ int s_flag;
+  __shared__ double sfq[2 * NFC + 2];                     // {f, f^2} per frequency slot + {fmin, fmax} (broadcast reads)
 
-  // uniform frequency chunk; lanes beyond nfc reuse the last valid one (results discarded)
-  double fq[NFC];
-#pragma unroll
-  for (int j = 0; j < NFC; ++j) fq[j] = cfrq[jbase + min(j, nfc - 1)];
-
+  // uniform frequency chunk; slots beyond nfc reuse the last valid one (results discarded)
   if (tid == 0) s_flag = 0;
+  if (tid < NFC) { const double f = cfrq[jbase + min(tid, nfc - 1)]; sfq[2 * tid] = f; sfq[2 * tid + 1] = f * f; }
+  if (tid == WAVE - 1) {
+    double lo = cfrq[jbase], hi = lo;
+    for (int j = 1; j < nfc; ++j) { const double f = cfrq[jbase + j]; lo = fmin(lo, f); hi = fmax(hi, f); }
+    sfq[2 * NFC] = lo; sfq[2 * NFC + 1] = hi;
+  }
   __syncthreads();
 
   const bool active = tid < nlev;
@@ -400,19 +498,8 @@ k_tb_fused(const FusedArgs A) {
   if (active && (isnan(zi) || isnan(pi) || isnan(ti) || isnan(rhi))) atomicOr(&s_flag, 1);
   __syncthreads();
   if (s_flag) {                               // check_for_nans: outputs stay NaN, valid = 0
-    const double qnan = __builtin_nan("");
-    for (int it = tid; it < nfc * nang; it += nthreads) {
-      const int j = it / nang, a = it % nang;
-      const int64_t o = (prof * nang + a) * A.nf + jbase + j;
-      A.tb[o] = qnan;
-      if (A.tbatm) A.tbatm[o] = qnan;
-      if (A.tmr) A.tmr[o] = qnan;
-      if (A.tauwet) A.tauwet[o] = qnan;
-      if (A.taudry) A.taudry[o] = qnan;
-    }
-    if (A.taulay) for (int it = tid; it < nfc * nlev; it += nthreads)
-      A.taulay[(prof * A.nf + jbase + it / nlev) * nlev + it % nlev] = qnan;
-    if (tid == 0) A.valid[prof] = 0;          // valid[] is preset to 1 by the host
+    blank_outputs(A, prof, jbase, nfc, tid, nthreads);
+    if (tid == 0) A.valid[prof] = 0;
     return;
   }
 
@@ -421,134 +508,135 @@ k_tb_fused(const FusedArgs A) {
   {
     const double e = goff_gratch_e(ti, rhi);
     const LevelState L = level_state(pi, ti, e);
-    h2o_absorb<NFC>(M, L, fq, awet);
-    dry_absorb<NFC>(M, L, fq, adry);
+    h2o_absorb<NFC>(M, L, sfq, awet);
+    dry_absorb<NFC>(M, L, sfq, adry);
   }
-  if (active) {
+  // neighbour level i-1: lane-1 through the crossbar, wave seams through a 2*NFC-double edge row
+  if (lane == WAVE - 1) {
 #pragma unroll
-    for (int j = 0; j < NFC; ++j) { tau[j * ld + tid] = awet[j]; bof[j * ld + tid] = adry[j]; }
+    for (int j = 0; j < NFC; ++j) { edge[wave * 2 * NFC + j] = awet[j]; edge[wave * 2 * NFC + NFC + j] = adry[j]; }
   }
   __syncthreads();
-  // layer optical depth (zenith): needs level i-1
   double tw[NFC], td[NFC];
   bool neg = false;
-  const double z0 = A.z[prof * nlev];         // execute() works in height above the antenna
-  const double dz = (active && tid > 0) ? ((zi - z0) - (A.z[off - 1] - z0)) : 0.0;
-  if (active && tid > 0) {
+  {
+    const double z0 = A.z[prof * nlev];       // execute() works in height above the antenna
+    const double dz = (active && tid > 0) ? ((zi - z0) - (A.z[off - 1] - z0)) : 0.0;
+    const bool seam = (lane == 0) && (wave > 0);
+    const bool has_prev = active && tid > 0;
 #pragma unroll
     for (int j = 0; j < NFC; ++j) {
-      tw[j] = layer_value(awet[j], tau[j * ld + tid - 1], neg) * dz;
-      td[j] = layer_value(adry[j], bof[j * ld + tid - 1], neg) * dz;
+      double pw = __shfl_up(awet[j], 1, WAVE);
+      double pd = __shfl_up(adry[j], 1, WAVE);
+      if (seam) { pw = edge[(wave - 1) * 2 * NFC + j]; pd = edge[(wave - 1) * 2 * NFC + NFC + j]; }
+      tw[j] = has_prev ? layer_value(awet[j], pw, neg) * dz : 0.0;
+      td[j] = has_prev ? layer_value(adry[j], pd, neg) * dz : 0.0;
     }
-  } else {
-#pragma unroll
-    for (int j = 0; j < NFC; ++j) { tw[j] = 0.0; td[j] = 0.0; }
   }
   if (neg) atomicOr(&s_flag, 2);
   __syncthreads();
   if (s_flag) {                               // pyrtlib raises ValueError here: flag 2, NaN out
-    const double qnan = __builtin_nan("");
-    for (int it = tid; it < nfc * nang; it += nthreads) {
-      const int j = it / nang, a = it % nang;
-      const int64_t o = (prof * nang + a) * A.nf + jbase + j;
-      A.tb[o] = qnan;
-      if (A.tbatm) A.tbatm[o] = qnan;
-      if (A.tmr) A.tmr[o] = qnan;
-      if (A.tauwet) A.tauwet[o] = qnan;
-      if (A.taudry) A.taudry[o] = qnan;
-    }
-    if (A.taulay) for (int it = tid; it < nfc * nlev; it += nthreads)
-      A.taulay[(prof * A.nf + jbase + it / nlev) * nlev + it % nlev] = qnan;
+    blank_outputs(A, prof, jbase, nfc, tid, nthreads);
     if (tid == 0) A.valid[prof] = 2;
     return;
   }
   const double hk = 1e9 * M->planck_h / M->boltzmann_k;
-  if (active) {
+  if (A.taulay && active) {
 #pragma unroll
-    for (int j = 0; j < NFC; ++j) {
-      tau[j * ld + tid] = tw[j] + td[j];
-      bof[j * ld + tid] = fdiv(1.0, exp(fdiv(fq[j] * hk, ti)) - 1.0);
-    }
-    if (A.taulay) {
-#pragma unroll
-      for (int j = 0; j < NFC; ++j)
-        if (j < nfc) A.taulay[(prof * A.nf + jbase + j) * nlev + tid] = tw[j] + td[j];
-    }
+    for (int j = 0; j < NFC; ++j)
+      if (j < nfc) A.taulay[(prof * A.nf + jbase + j) * nlev + tid] = tw[j] + td[j];
   }
-  // optional zenith opacity sums (tauwet / taudry columns)
-  double swet[NFC], sdry[NFC];
   const bool want_tau = (A.tauwet != nullptr) || (A.taudry != nullptr);
-  if (want_tau) {
-#pragma unroll
-    for (int j = 0; j < NFC; ++j) {
-      swet[j] = block_sum(tw[j], scratch, tid, nthreads);
-      sdry[j] = block_sum(td[j], scratch, tid, nthreads);
-    }
-  }
-  __syncthreads();
-
-  // ---- phase K2: slant-path RTE (RTEquation.planck, from_sat = False [EXT]) ----
-  const int npairs = nfc * nang;
   const int nseg = A.g.nseg, seglen = A.g.seglen;
-  const int items = npairs * nseg;
-  for (int it = tid; it < items; it += nthreads) {
-    const int seg = it / npairs;
-    const int pr = it - seg * npairs;
-    const int j = pr / nang;
-    const int a = pr - j * nang;
-    const double am = cam[a];
-    const int lo = 1 + seg * seglen;
-    const int hi = min(lo + seglen, nlev);
-    const double* tj = tau + j * ld;
-    const double* bj = bof + j * ld;
-    double T = 1.0, B = 0.0, S = 0.0;
-    double bprev = (lo < nlev) ? bj[lo - 1] : 0.0;
-    for (int i = lo; i < hi; ++i) {
-      const double tl = tj[i] * am;
-      const double E = exp(-tl);
-      const double bi = bj[i];
-      const double lay = fdiv(__builtin_fma(bi, E, bprev), 1.0 + E);
-      B = __builtin_fma(lay * T, 1.0 - E, B);
-      T *= E;
-      S += tl;
-      bprev = bi;
-    }
-    part[3 * it + 0] = B; part[3 * it + 1] = T; part[3 * it + 2] = S;
-  }
-  __syncthreads();
-  for (int pr = tid; pr < npairs; pr += nthreads) {
-    const int j = pr / nang;
-    const int a = pr - j * nang;
-    double B = 0.0, T = 1.0, S = 0.0;
-    for (int s = 0; s < nseg; ++s) {
-      const double* q = part + 3 * (s * npairs + pr);
-      B = __builtin_fma(T, q[0], B);
-      T *= q[1];
-      S += q[2];
-    }
-    const double hvk = cfrq[jbase + j] * hk;
-    double boftotl, boftmr;
-    if (S < TAUMAX) {
-      const double ex = exp(-S);
-      const double bbg = fdiv(1.0, exp(fdiv(hvk, M->t_cosmic)) - 1.0);
-      boftotl = __builtin_fma(bbg, ex, B);
-      boftmr = fdiv(B, 1.0 - ex);
-    } else {
-      boftotl = B; boftmr = B;
-    }
-    const int64_t o = (prof * nang + a) * A.nf + jbase + j;
-    A.tb[o] = fdiv(hvk, log(1.0 + fdiv(1.0, boftotl)));
-    if (A.tbatm) A.tbatm[o] = fdiv(hvk, log(1.0 + fdiv(1.0, B)));
-    if (A.tmr) A.tmr[o] = fdiv(hvk, log(1.0 + fdiv(1.0, boftmr)));
-    if (want_tau) {
-      const double am = cam[a];
-      double sw = 0.0, sd = 0.0;
+
+  // ---- phase K2: slant-path RTE (RTEquation.planck, from_sat = False [EXT]), NFK rows at a time ----
 #pragma unroll
-      for (int jj = 0; jj < NFC; ++jj) if (jj == j) { sw = swet[jj]; sd = sdry[jj]; }
-      if (A.tauwet) A.tauwet[o] = sw * am;
-      if (A.taudry) A.taudry[o] = sd * am;
+  for (int h = 0; h < NPASS; ++h) {
+    const int nfk = min(NFK, nfc - h * NFK);            // frequencies live in this pass (uniform)
+    if (nfk <= 0) break;
+    if (h > 0) __syncthreads();                          // previous pass has finished reading LDS
+    if (active) {
+#pragma unroll
+      for (int jj = 0; jj < NFK; ++jj) {
+        const int j = h * NFK + jj;
+        tau[jj * ld + tid] = tw[j] + td[j];
+        bof[jj * ld + tid] = fdiv(1.0, exp(fdiv(sfq[2 * j] * hk, ti)) - 1.0);
+      }
+    }
+    // optional zenith opacity sums (tauwet / taudry columns); deterministic order
+    double swet[NFK], sdry[NFK];
+    if (want_tau) {
+#pragma unroll
+      for (int jj = 0; jj < NFK; ++jj) {
+        swet[jj] = block_sum(tw[h * NFK + jj], scratch, tid, nthreads);
+        sdry[jj] = block_sum(td[h * NFK + jj], scratch, tid, nthreads);
+      }
+    }
+    __syncthreads();
+
+    const int npairs = nfk * nang;
+    const int items = (MWRT_ABLATE & 8) ? 0 : npairs * nseg;
+    for (int it = tid; it < items; it += nthreads) {
+      const int seg = it / npairs;
+      const int pr = it - seg * npairs;
+      const int jj = pr / nang;
+      const int a = pr - jj * nang;
+      const double am = cam[a];
+      const int lo = 1 + seg * seglen;
+      const int hi = min(lo + seglen, nlev);
+      const double* tj = tau + jj * ld;
+      const double* bj = bof + jj * ld;
+      double T = 1.0, B = 0.0, S = 0.0;
+      double bprev = (lo < nlev) ? bj[lo - 1] : 0.0;
+      for (int i = lo; i < hi; ++i) {
+        const double tl = tj[i] * am;
+        const double E = exp(-tl);
+        const double bi = bj[i];
+        const double lay = fdiv(__builtin_fma(bi, E, bprev), 1.0 + E);
+        B = __builtin_fma(lay * T, 1.0 - E, B);
+        T *= E;
+        S += tl;
+        bprev = bi;
+      }
+      part[3 * it + 0] = B; part[3 * it + 1] = T; part[3 * it + 2] = S;
+    }
+    __syncthreads();
+    for (int pr = tid; pr < npairs; pr += nthreads) {
+      const int jj = pr / nang;
+      const int a = pr - jj * nang;
+      const int j = h * NFK + jj;
+      double B = 0.0, T = 1.0, S = 0.0;
+      for (int sg = 0; sg < nseg; ++sg) {
+        const double* q = part + 3 * (sg * npairs + pr);
+        B = __builtin_fma(T, q[0], B);
+        T *= q[1];
+        S += q[2];
+      }
+      const double hvk = cfrq[jbase + j] * hk;
+      double boftotl, boftmr;
+      if (S < TAUMAX) {
+        const double ex = exp(-S);
+        const double bbg = fdiv(1.0, exp(fdiv(hvk, M->t_cosmic)) - 1.0);
+        boftotl = __builtin_fma(bbg, ex, B);
+        boftmr = fdiv(B, 1.0 - ex);
+      } else {
+        boftotl = B; boftmr = B;
+      }
+      const int64_t o = (prof * nang + a) * A.nf + jbase + j;
+      A.tb[o] = fdiv(hvk, log(1.0 + fdiv(1.0, boftotl)));
+      if (A.tbatm) A.tbatm[o] = fdiv(hvk, log(1.0 + fdiv(1.0, B)));
+      if (A.tmr) A.tmr[o] = fdiv(hvk, log(1.0 + fdiv(1.0, boftmr)));
+      if (want_tau) {
+        const double am = cam[a];
+        double sw = 0.0, sd = 0.0;
+#pragma unroll
+        for (int q2 = 0; q2 < NFK; ++q2) if (q2 == jj) { sw = swet[q2]; sd = sdry[q2]; }
+        if (A.tauwet) A.tauwet[o] = sw * am;
+        if (A.taudry) A.taudry[o] = sd * am;
+      }
     }
   }
+  if (A.write_valid && tid == 0) A.valid[prof] = 1;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -571,17 +659,22 @@ k_absorb(const AbsorbArgs A) {
   const int nfc = min(NFC, A.nf - jbase);
   const cmodel M = (cmodel)A.M;
   const cdoubles cfrq = (cdoubles)A.frq;
-  double fq[NFC];
-#pragma unroll
-  for (int j = 0; j < NFC; ++j) fq[j] = cfrq[jbase + min(j, nfc - 1)];
+  __shared__ double sfq[2 * NFC + 2];
+  if (tid < NFC) { const double f = cfrq[jbase + min(tid, nfc - 1)]; sfq[2 * tid] = f; sfq[2 * tid + 1] = f * f; }
+  if (tid == WAVE - 1) {
+    double lo = cfrq[jbase], hi = lo;
+    for (int j = 1; j < nfc; ++j) { const double f = cfrq[jbase + j]; lo = fmin(lo, f); hi = fmax(hi, f); }
+    sfq[2 * NFC] = lo; sfq[2 * NFC + 1] = hi;
+  }
+  __syncthreads();
   const bool active = tid < A.nlev;
   const int64_t off = prof * A.nlev + (active ? tid : 0);
   const double pi = A.p[off], ti = A.t[off], rhi = A.rh[off];
   double awet[NFC], adry[NFC];
   const double e = goff_gratch_e(ti, rhi);
   const LevelState L = level_state(pi, ti, e);
-  h2o_absorb<NFC>(M, L, fq, awet);
-  dry_absorb<NFC>(M, L, fq, adry);
+  h2o_absorb<NFC>(M, L, sfq, awet);
+  dry_absorb<NFC>(M, L, sfq, adry);
   if (active) {
 #pragma unroll
     for (int j = 0; j < NFC; ++j) {
