@@ -131,6 +131,14 @@ def main():
         kernel_ms = kernel_ms_total / max(launches, 1)
         abytes = roofline.algorithmic_bytes(nprof, nlev, nf, nang)
         aflops = roofline.algorithmic_flops(nprof, nlev, nf, nang, tables.n_o2, tables.n_h2o)
+        traffic, traffic_src = None, None
+        tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        if os.path.exists(tpath) and nprof == 1000 and args.model == "R24":
+            tj = json.load(open(tpath))
+            ent = tj.get("configs", {}).get(str(args.config))
+            if ent:
+                traffic = ent["traffic_bytes"]
+                traffic_src = f"rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE, round {tj.get('round')}, profiles/pmc_traffic.json"
         gbs = abytes / (kernel_ms * 1e-3) / 1e9
         tflops = aflops / (kernel_ms * 1e-3) / 1e12
         res = {
@@ -147,7 +155,7 @@ def main():
                        "nprof_per_gpu": nprof, "nlev": nlev, "nf": nf, "nang": nang, "model": args.model,
                        "sharding": f"profiles x{world}, final all_gather of {min(K, slots)} result batches"},
             "roofline": {"bound": "hbm", "achieved": gbs, "peak": roofline.HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": gbs / roofline.HBM_PEAK_GBS, "traffic": None,
+                         "frac": gbs / roofline.HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                          "kernel": "k_tb_fused", "kernel_ms": kernel_ms, "launches_timed": launches,
                          "algorithmic_bytes_per_launch": abytes,
                          "note": "fp64-VALU bound, not HBM bound (elementwise + scan, no MFMA): the real ceiling "
