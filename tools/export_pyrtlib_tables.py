@@ -1,0 +1,73 @@
+#!/usr/bin/env python3
+"""Dump pyrtlib's OWN spectroscopic tables into this package's ModelTables JSON.
+
+Run this where pyrtlib is installed (it is NOT in the build image, so this script could not be
+executed there: treat it as a starting point and check the attribute names against your
+pyrtlib version).  It closes the "parity unpinned" gap of DESIGN.md section 2 with data, not code:
+
+    python tools/export_pyrtlib_tables.py R24 > R24_pyrtlib.json
+    >>> from mwr_fast_forward_operators_and_lbls_amd import spectroscopy as sp
+    >>> sp.register_model(sp.ModelTables.from_json(open("R24_pyrtlib.json").read()), overwrite=True)
+
+Only the line lists and scalar switches are taken from pyrtlib; the arithmetic stays ours.
+"""
+import json
+import sys
+
+import numpy as np
+
+
+def arr(ll, *names, n=None, scale=1.0):
+    for nm in names:
+        if hasattr(ll, nm):
+            a = np.atleast_1d(np.asarray(getattr(ll, nm), dtype=float)) * scale
+            return a.tolist()
+    return [0.0] * n
+
+
+def main(model: str):
+    from pyrtlib.absorption_model import H2OAbsModel, O2AbsModel  # noqa: F401 (needs pyrtlib)
+
+    H2OAbsModel.model = model
+    H2OAbsModel.set_ll()
+    O2AbsModel.model = model
+    O2AbsModel.set_ll()
+    h, o = H2OAbsModel.h2oll, O2AbsModel.o2ll
+    nh, no = len(h.fl), len(o.f)
+    old = model in ("R98", "R03", "R16", "R17")
+    out = {
+        "name": model, "provenance": f"exported from pyrtlib ({model})",
+        "h2o_reftcon": float(h.reftcon), "h2o_reftline": float(h.reftline),
+        "h2o_cf": float(h.cf), "h2o_xcf": float(h.xcf), "h2o_cs": float(h.cs), "h2o_xcs": float(h.xcs),
+        "h2o_pvap_div": 217.0 if old else 216.68,
+        "h2o_den_coef": 3.335e16 if model in ("R98", "R03", "R16") else 3.344e16,
+        "h2o_shift_mode": 0 if model == "R98" else 2,
+        "h2o": {
+            "fl": arr(h, "fl"), "s1": arr(h, "s1"), "b2": arr(h, "b2"),
+            "w0": arr(h, "w0", "w3"), "x": arr(h, "x"), "w0s": arr(h, "w0s", "ws"), "xs": arr(h, "xs"),
+            "sh": arr(h, "sh", n=nh), "xh": arr(h, "xh", n=nh), "shs": arr(h, "shs", n=nh), "xhs": arr(h, "xhs", n=nh),
+            "aair": arr(h, "aair", n=nh), "aself": arr(h, "aself", n=nh),
+            "w2": arr(h, "w2", n=nh), "xw2": arr(h, "xw2", n=nh), "w2s": arr(h, "w2s", n=nh), "xw2s": arr(h, "xw2s", n=nh),
+            "d2": arr(h, "d2", n=nh), "d2s": arr(h, "d2s", n=nh),
+        },
+        "o2_x": float(getattr(o, "x", 0.8 if old else 0.754)), "o2_wb300": float(getattr(o, "wb300", 0.56)),
+        "o2_pvap_div": 217.0 if old else 216.68, "o2_wv_factor": 1.1 if old else 1.2,
+        "o2_nonres": 1.6e-17 if model in ("R98", "R03", "R16") else 1.584e-17,
+        "o2_coef": 0.5034e12 / 3.14159 if model in ("R98", "R03", "R16") else 1.6097e11,
+        "o2_mix_mode": 0 if old else 1, "o2_line1_dens": 1 if model == "R98" else 0,
+        "o2": {
+            "f": arr(o, "f"), "s300": arr(o, "s300"), "be": arr(o, "be"), "w300": arr(o, "w300"),
+            "y0": arr(o, "y0", "y300"), "y1": arr(o, "y1", "v"),
+            "g0": arr(o, "g0", n=no), "g1": arr(o, "g1", n=no), "dnu0": arr(o, "dnu0", n=no), "dnu1": arr(o, "dnu1", n=no),
+        },
+        "n2_l": 6.4e-14 if model == "R98" else (6.5e-14 if old else 9.95e-14),
+        "n2_m": 3.55 if model == "R98" else (3.6 if old else 3.22),
+        "n2_n": 1.0 if model == "R98" or not old else 1.29,
+        "n2_fdep": 0 if model == "R98" else 1, "n2_ptot": 1 if old else 0,
+    }
+    print(json.dumps(out, indent=1))
+    print("# CHECK the scalar switches above against your pyrtlib's absorption_model.py", file=sys.stderr)
+
+
+if __name__ == "__main__":
+    main(sys.argv[1] if len(sys.argv) > 1 else "R24")
