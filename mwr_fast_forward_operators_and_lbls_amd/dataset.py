@@ -55,6 +55,43 @@ class Dataset:
         meta = {k: {"dims": list(v.dims), "attrs": v.attrs} for k, v in self._vars.items()}
         np.savez_compressed(path, __meta__=np.array(json.dumps({"vars": meta, "attrs": self.attrs})), **payload)
 
+    # -- NetCDF-3 classic via scipy (readable by xarray's scipy engine, so the reference's
+    #    downstream readers, summarize_proc_results.py:76-90, can open what we write).  The
+    #    reference itself writes NETCDF4_CLASSIC (:211), an HDF5 container this image cannot
+    #    produce or read (no netCDF4 / h5py).
+    def to_netcdf3(self, path: str):
+        from scipy.io import netcdf_file
+        with netcdf_file(path, "w", version=2) as f:
+            dims = {}
+            for v in self._vars.values():
+                for d, n in zip(v.dims, v.values.shape):
+                    if dims.setdefault(d, n) != n:
+                        raise ValueError(f"dimension {d} has conflicting lengths")
+            for d, n in dims.items():
+                f.createDimension(d, n)
+            for k, v in self._vars.items():
+                arr = v.values
+                if arr.dtype.kind in "iu" and arr.dtype.itemsize > 4:
+                    arr = arr.astype(np.float64)         # NetCDF-3 has no 64-bit integers
+                var = f.createVariable(k, arr.dtype.newbyteorder("=").char if arr.dtype.kind != "f" else ("d" if arr.dtype.itemsize == 8 else "f"), v.dims)
+                var[...] = arr
+                for ak, av in v.attrs.items():
+                    setattr(var, ak, av)
+            for ak, av in self.attrs.items():
+                setattr(f, ak, av)
+
+    @classmethod
+    def from_netcdf3(cls, path: str) -> "Dataset":
+        from scipy.io import netcdf_file
+        ds = cls()
+        with netcdf_file(path, "r", mmap=False) as f:
+            for k, var in f.variables.items():
+                attrs = {a: (getattr(var, a).decode() if isinstance(getattr(var, a), bytes) else getattr(var, a))
+                         for a in var._attributes}
+                ds._vars[k] = Variable(tuple(var.dimensions), np.array(var[...]), attrs)
+            ds.attrs = {a: (v.decode() if isinstance(v, bytes) else v) for a, v in f._attributes.items()}
+        return ds
+
     @classmethod
     def from_npz(cls, path: str) -> "Dataset":
         with np.load(path, allow_pickle=False) as f:

@@ -129,15 +129,22 @@ def open_dataset(path: str):
         return Dataset.from_npz(path)
     try:
         import xarray as xr
-    except ImportError as exc:
-        raise ImportError("reading NetCDF needs xarray/netCDF4, which this image lacks; "
-                          "convert to .npz (dataset.Dataset.to_npz)") from exc
+    except ImportError:
+        with open(path, "rb") as fh:
+            magic = fh.read(4)
+        if magic[:3] == b"CDF":                     # NetCDF-3 classic / 64-bit offset: scipy can read it
+            return Dataset.from_netcdf3(path)
+        raise ImportError("this file is NetCDF-4/HDF5 and reading it needs xarray + netCDF4, which this image "
+                          "lacks; convert to NetCDF-3 or .npz (dataset.Dataset)") from None
     return xr.open_dataset(path)
 
 
 def write_dataset(ds, path: str):
     if isinstance(ds, Dataset):
-        ds.to_npz(path if path.endswith(".npz") else path + ".npz")
+        if path.endswith(".npz"):
+            ds.to_npz(path)
+        else:
+            ds.to_netcdf3(path)                       # NetCDF-3 classic: what scipy can write here
     else:
         ds.to_netcdf(path, format="NETCDF4_CLASSIC")      # reference :211
 

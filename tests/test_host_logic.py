@@ -152,3 +152,18 @@ def test_model_tables_json_roundtrip_and_registry():
     assert sp.get_model("R20_custom") is custom
     with pytest.raises(ValueError):
         sp.register_model(custom)
+
+
+def test_netcdf3_roundtrip_and_cli_io(tmp_path):
+    ds, _ = make_ds(ntime=2, ncrop=2, nlev=20, elev=(90.0, 30.0))
+    out = pp.derive_TBs4PyRTlib(ds, None, _engine=oracle_engine)
+    path = str(tmp_path / "tbs.nc")
+    pp.write_dataset(out, path)
+    with open(path, "rb") as fh:
+        assert fh.read(3) == b"CDF"
+    back = pp.open_dataset(path)
+    v = back["TBs_PyRTlib_R24"]
+    assert v.dims == ('time', 'N_Channels', 'elevation', 'Crop')
+    assert np.array_equal(v.values, out["TBs_PyRTlib_R24"].values)
+    assert v.attrs["units"] == "K" and v.attrs["standard_name"] == "brightness_temperature"
+    assert np.array_equal(back["Level_Pressure"].values, ds["Level_Pressure"].values)
