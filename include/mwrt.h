@@ -139,6 +139,11 @@ int mwrt_absorption_batch_device(mwrt_context* ctx, const mwrt_model* model,
                                  int32_t nf, const double* frq_ghz,
                                  double* d_awet_out, double* d_adry_out, void* stream);
 
+/* Kernel choice for mwrt_tb_batch*: 0 = automatic (currently always the lane = level fused kernel),
+ * 1 = always fused, 2 = the lane = frequency "spectral" kernel (at most 16 angles per call).
+ * Results agree to rounding; this exists for tests and measurements. */
+int mwrt_set_kernel_policy(mwrt_context* ctx, int policy);
+
 /* Block until everything queued on the context's stream (or `stream`) has finished. */
 int mwrt_synchronize(mwrt_context* ctx, void* stream);
 

@@ -52,6 +52,7 @@ SIGNATURES = {
                                             _vp, _vp, ctypes.POINTER(MwrtTbExtras), _vp]),
     "mwrt_absorption_batch": (ctypes.c_int, [_vp, _vp, _i64, _i32, _vp, _vp, _vp, _i32, _vp, _vp, _vp]),
     "mwrt_absorption_batch_device": (ctypes.c_int, [_vp, _vp, _i64, _i32, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp]),
+    "mwrt_set_kernel_policy": (ctypes.c_int, [_vp, ctypes.c_int]),
     "mwrt_synchronize": (ctypes.c_int, [_vp, _vp]),
     "mwrt_set_timing": (ctypes.c_int, [_vp, ctypes.c_int]),
     "mwrt_timing_collect": (ctypes.c_int, [_vp, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int32)]),
@@ -233,6 +234,10 @@ class Context:
             self._handle, self.model(model), int(nprof), int(nlev), _ptr(d_p), _ptr(d_t), _ptr(d_rh),
             frq.size, _ptr(frq), _ptr(d_awet), _ptr(d_adry),
             ctypes.c_void_p(stream) if stream else None), "mwrt_absorption_batch_device")
+
+    def set_kernel_policy(self, policy: int):
+        """0 auto, 1 always the lane=level fused kernel, 2 always the lane=frequency spectral kernel."""
+        self._check(self._lib.mwrt_set_kernel_policy(self._handle, int(policy)), "mwrt_set_kernel_policy")
 
     def synchronize(self, stream: int = 0):
         self._check(self._lib.mwrt_synchronize(self._handle, ctypes.c_void_p(stream) if stream else None),

@@ -48,6 +48,7 @@ struct mwrt_context {
   int device = 0;
   hipStream_t stream = nullptr;
   int lds_max = 65536;
+  int kernel_policy = 0;        // 0 auto, 1 fused, 2 spectral
   // small per-call parameter arrays (frq, airmass) cached on the device by content
   DevBuf d_frq, d_am;
   std::vector<double> h_frq, h_am;
@@ -160,6 +161,40 @@ int launch_fused(mwrt_context* c, FusedArgs a, int64_t nprof, hipStream_t st) {
   timing_end(c, st);
   HIP_TRY(hipGetLastError());
   return MWRT_OK;
+}
+
+template <int NA>
+int launch_spectral_na(mwrt_context* c, const SpectralArgs& a, int64_t nprof, int threads, size_t lds, hipStream_t st) {
+  dim3 grid((unsigned)nprof, (unsigned)((a.nf + threads - 1) / threads)), block(threads);
+  auto k = k_tb_spectral<NA>;
+  HIP_TRY(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  timing_begin(c, st);
+  hipLaunchKernelGGL(k, grid, block, lds, st, a);
+  timing_end(c, st);
+  HIP_TRY(hipGetLastError());
+  return MWRT_OK;
+}
+
+int launch_spectral(mwrt_context* c, const mwrt_model* m, SpectralArgs a, int64_t nprof, hipStream_t st) {
+  int n_sd = 0;
+  for (int k = 0; k < m->h_desc.n_h2o; ++k) n_sd += m->h_desc.h2o_w2[k] > 0.0 ? 1 : 0;
+  a.n_sd = n_sd;
+  a.rec = SP_LEVEL_SCALARS + 4 * m->h_desc.n_o2 + 4 * m->h_desc.n_h2o + 6 * n_sd;
+  const size_t per_level = sizeof(double) * (size_t)(a.rec + SPO_COUNT);
+  const size_t budget = std::min<size_t>((size_t)c->lds_max, 40960);    // 4 workgroups per CU
+  int lc = (int)(budget / per_level);
+  if (lc < 1) return fail(MWRT_ERR_UNSUPPORTED, "line tables too large for the spectral kernel's LDS record");
+  if (lc > a.nlev) lc = a.nlev;
+  a.lc = lc;
+  const size_t lds = per_level * lc;
+  const int threads = std::min(256, ((a.nf + WAVE - 1) / WAVE) * WAVE);
+  HIP_TRY(hipMemsetAsync(a.valid, 1, (size_t)nprof, st));
+  if (a.nang <= 1) return launch_spectral_na<1>(c, a, nprof, threads, lds, st);
+  if (a.nang <= 4) return launch_spectral_na<4>(c, a, nprof, threads, lds, st);
+  if (a.nang <= 7) return launch_spectral_na<7>(c, a, nprof, threads, lds, st);
+  if (a.nang <= 10) return launch_spectral_na<10>(c, a, nprof, threads, lds, st);
+  if (a.nang <= 16) return launch_spectral_na<16>(c, a, nprof, threads, lds, st);
+  return fail(MWRT_ERR_UNSUPPORTED, "spectral kernel supports at most 16 angles per call");
 }
 
 template <int NFC>
@@ -306,6 +341,18 @@ int mwrt_tb_batch_device(mwrt_context* c, const mwrt_model* m, int64_t nprof, in
   rc = upload_small(c, c->d_frq, c->h_frq, frq, nf, st); if (rc) return rc;
   rc = upload_small(c, c->d_am, c->h_am, am.data(), nang, st); if (rc) return rc;
 
+  // automatic = fused: measured on MI355X the spectral kernel only ties it on the 1000-frequency grid
+  // (profiles/r01_finegrid.txt), so it stays opt-in until it wins
+  const bool spectral = c->kernel_policy == 2;
+  if (spectral) {
+    SpectralArgs sa{};
+    sa.M = m->d_desc; sa.z = d_z; sa.p = d_p; sa.t = d_t; sa.rh = d_rh;
+    sa.frq = c->d_frq.as<double>(); sa.airmass = c->d_am.as<double>();
+    sa.tb = d_tb; sa.valid = d_valid;
+    if (ex) { sa.tbatm = ex->tbatm; sa.tmr = ex->tmr; sa.tauwet = ex->tauwet; sa.taudry = ex->taudry; sa.taulay = ex->taulay; }
+    sa.nlev = nlev; sa.nf = nf; sa.nang = nang;
+    return launch_spectral(c, m, sa, nprof, st);
+  }
   FusedArgs a{};
   a.M = m->d_desc; a.z = d_z; a.p = d_p; a.t = d_t; a.rh = d_rh;
   a.frq = c->d_frq.as<double>(); a.airmass = c->d_am.as<double>();
@@ -362,6 +409,17 @@ int mwrt_tb_batch(mwrt_context* c, const mwrt_model* m, int64_t nprof, int32_t n
       if (host_ex[k]) HIP_TRY(hipMemcpyAsync(host_ex[k], dptr[k], (k < 4 ? nout : nlay) * sizeof(double), hipMemcpyDeviceToHost, st));
   }
   HIP_TRY(hipStreamSynchronize(st));
+  // a profile flagged 2 (negative absorption: pyrtlib raises for the whole execute()) is blanked
+  // as a whole, whichever frequency chunk met it
+  const double qnan = std::nan("");
+  for (int64_t i = 0; i < nprof; ++i) {
+    if (valid[i] != 2) continue;
+    for (size_t o = 0; o < (size_t)nang * nf; ++o) {
+      tb[(size_t)i * nang * nf + o] = qnan;
+      for (int k = 0; k < 4; ++k) if (host_ex[k]) host_ex[k][(size_t)i * nang * nf + o] = qnan;
+    }
+    if (host_ex[4]) for (size_t o = 0; o < (size_t)nf * nlev; ++o) host_ex[4][(size_t)i * nf * nlev + o] = qnan;
+  }
   return MWRT_OK;
 }
 
@@ -408,6 +466,12 @@ int mwrt_absorption_batch(mwrt_context* c, const mwrt_model* m, int64_t nprof, i
   HIP_TRY(hipMemcpyAsync(awet, dout, nout * sizeof(double), hipMemcpyDeviceToHost, st));
   HIP_TRY(hipMemcpyAsync(adry, dout + nout, nout * sizeof(double), hipMemcpyDeviceToHost, st));
   HIP_TRY(hipStreamSynchronize(st));
+  return MWRT_OK;
+}
+
+int mwrt_set_kernel_policy(mwrt_context* c, int policy) {
+  if (!c || policy < 0 || policy > 2) return fail(MWRT_ERR_INVALID_ARGUMENT, "policy must be 0, 1 or 2");
+  c->kernel_policy = policy;
   return MWRT_OK;
 }
 

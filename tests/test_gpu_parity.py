@@ -230,3 +230,81 @@ def test_wrapper_end_to_end(gpu_ctx):
         assert a.shape == (3, 14, 10, 2)
         assert np.array_equal(np.isnan(a), np.isnan(b)) and np.isnan(a[2, :, :, 1]).all()
         assert np.nanmax(np.abs(a - b)) <= TOL_K
+
+
+@pytest.mark.parametrize("name", ["R98", "R17", "R24"])
+@pytest.mark.parametrize("nang", [1, 3, 7, 10, 13])
+def test_spectral_kernel_matches_oracle(gpu_ctx, name, nang):
+    """lane = frequency kernel (forced) on the HATPRO set and ragged angle counts."""
+    P = pr.synthetic_profiles(3, 41)
+    ang = np.linspace(90.0, 4.2, nang)
+    gpu_ctx.set_kernel_policy(2)
+    try:
+        tb, valid, ex = gpu_ctx.tb_batch(name, P["z"], P["p"], P["t"], P["rh"], pr.HATPRO_FRQS, ang, extras=True)
+    finally:
+        gpu_ctx.set_kernel_policy(0)
+    assert (valid == 1).all()
+    ref, taulay = oracle_tb(sp.get_model(name), P, 2, pr.HATPRO_FRQS, ang)
+    assert np.abs(tb[2] - ref["tbtotal"]).max() <= TOL_K
+    assert np.abs(ex["tbatm"][2] - ref["tbatm"]).max() <= TOL_K
+    assert np.abs(ex["tmr"][2] - ref["tmr"]).max() <= TOL_K
+    assert np.allclose(ex["tauwet"][2], ref["tauwet"], rtol=1e-9)
+    assert np.allclose(ex["taudry"][2], ref["taudry"], rtol=1e-9)
+    assert np.allclose(ex["taulay"][2], taulay[:, 0, :] * np.sin(ang[0] * np.pi / 180), rtol=1e-9, atol=1e-16)
+
+
+def test_fine_grid_config5_shape(gpu_ctx):
+    """BASELINE config 5 shape (1000 frequencies 20-60 GHz x 7 elevations) at a reduced profile
+    count: spectral and fused kernels agree with each other everywhere and with the C oracle on a
+    frequency subset; NaN and level-count edges ride along."""
+    from oracle import c_oracle
+    frq = pr.fine_grid_frequencies(1000)
+    ang = pr.BENCH_ELEVATIONS_7
+    P = pr.synthetic_profiles(6, 5)
+    P["p"][4, 100] = np.nan
+    tb_f, v_f = gpu_ctx.tb_batch("R24", P["z"], P["p"], P["t"], P["rh"], frq, ang)      # auto = fused, 63 chunks
+    gpu_ctx.set_kernel_policy(2)
+    try:
+        tb_s, v_s = gpu_ctx.tb_batch("R24", P["z"], P["p"], P["t"], P["rh"], frq, ang)  # lane = frequency
+    finally:
+        gpu_ctx.set_kernel_policy(0)
+    assert v_s.tolist() == [1, 1, 1, 1, 0, 1] and v_f.tolist() == v_s.tolist()
+    assert np.isnan(tb_s[4]).all() and np.isnan(tb_f[4]).all()
+    keep = [0, 1, 2, 3, 5]
+    assert np.abs(tb_s[keep] - tb_f[keep]).max() <= 1e-9
+    sub = np.arange(0, 1000, 37)
+    m = sp.get_model("R24")
+    r = c_oracle.tb_profile(m, P["z"][1], P["p"][1], P["t"][1], P["rh"][1], frq[sub], ang)
+    assert np.abs(tb_s[1][:, sub] - r["tbtotal"].reshape(7, len(sub))).max() <= TOL_K
+    # frequencies sitting on line centres and on the 750-GHz cutoff of the 752-GHz line
+    special = np.array([22.23508, 60.3061, 118.7503, 2.03, 2.034, 183.310087])
+    tb_x, _ = gpu_ctx.tb_batch("R24", P["z"][:2], P["p"][:2], P["t"][:2], P["rh"][:2], special, ang[:2])
+    gpu_ctx.set_kernel_policy(2)
+    try:
+        tb_y, _ = gpu_ctx.tb_batch("R24", P["z"][:2], P["p"][:2], P["t"][:2], P["rh"][:2], special, ang[:2])
+    finally:
+        gpu_ctx.set_kernel_policy(0)
+    r = c_oracle.tb_profile(m, P["z"][0], P["p"][0], P["t"][0], P["rh"][0], special, ang[:2])
+    assert np.abs(tb_x[0] - r["tbtotal"].reshape(2, 6)).max() <= TOL_K
+    assert np.abs(tb_y[0] - r["tbtotal"].reshape(2, 6)).max() <= TOL_K
+
+
+@pytest.mark.parametrize("nlev", [2, 17, 18, 40, 300])
+def test_spectral_level_chunks(gpu_ctx, nlev):
+    """Level counts around the spectral kernel's LDS chunk length (17 levels for the 49+16-line tables)."""
+    if nlev >= 20:
+        P = pr.synthetic_profiles(2, 43, nlev=nlev)
+    else:
+        z = np.linspace(0.1, 12.0, nlev)[None, :].repeat(2, 0)
+        P = {"z": z, "p": 1000.0 * np.exp(-z / 7.5), "t": 288.0 - 6.0 * z, "rh": 0.5 + 0.0 * z}
+    frq = np.linspace(20.0, 60.0, 70)
+    ang = np.array([90.0, 10.0])
+    gpu_ctx.set_kernel_policy(2)
+    try:
+        tb, valid = gpu_ctx.tb_batch("R20", P["z"], P["p"], P["t"], P["rh"], frq, ang)
+    finally:
+        gpu_ctx.set_kernel_policy(0)
+    from oracle import c_oracle
+    r = c_oracle.tb_profile(sp.get_model("R20"), P["z"][1], P["p"][1], P["t"][1], P["rh"][1], frq, ang)
+    assert (valid == 1).all()
+    assert np.abs(tb[1] - r["tbtotal"].reshape(2, 70)).max() <= TOL_K
