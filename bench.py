@@ -60,6 +60,21 @@ def cpu_baseline(tables, P, frq, ang, budget_s=20.0):
             "all_cores": {"value": P["z"].shape[0] * ev / dtn, "cores": cores, "seconds": round(dtn, 2)}}, tb, n
 
 
+class _stdout_to_stderr:
+    """RCCL prints a version banner on fd 1 at communicator creation; the contract is ONE JSON line
+    on stdout, so native-library chatter is diverted to stderr while collectives are set up."""
+
+    def __enter__(self):
+        sys.stdout.flush()
+        self._saved = os.dup(1)
+        os.dup2(2, 1)
+
+    def __exit__(self, *exc):
+        sys.stdout.flush()
+        os.dup2(self._saved, 1)
+        os.close(self._saved)
+
+
 def main():
     args = parse()
     rank = int(os.environ.get("RANK", "0"))
@@ -76,9 +91,15 @@ def main():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    # MWRT_BENCH_FORCE_DIST=1 runs the collective path even with one rank (rehearsal on a 1-GPU box)
+    use_dist = world > 1 or os.environ.get("MWRT_BENCH_FORCE_DIST") == "1"
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)      # backend "nccl" is RCCL on ROCm
+        os.environ.setdefault("MASTER_PORT", "29531")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
+        with _stdout_to_stderr():
+            dist.init_process_group("nccl", device_id=dev)  # backend "nccl" is RCCL on ROCm
 
     frq = profiles.HATPRO_FRQS
     ang = np.array([90.0]) if args.config == 2 else profiles.BENCH_ELEVATIONS_7
@@ -98,14 +119,17 @@ def main():
                             d["rh"].data_ptr(), frq, ang, out[s % slots].data_ptr(), valid.data_ptr(), stream=stream)
 
     def barrier():
-        if world > 1:
+        if use_dist:
             dist.barrier()
 
     for s in range(W):
         step(s)
-    if world > 1:                                   # warm the collective too
+    if use_dist:                                    # warm the collective too
         parts = [torch.empty_like(out) for _ in range(world)]
-        dist.all_gather(parts, out)
+        with _stdout_to_stderr():
+            dist.all_gather(parts, out)
+            dist.barrier()
+            torch.cuda.synchronize()
     torch.cuda.synchronize()
     ctx.set_timing(True)
     barrier()
@@ -113,7 +137,7 @@ def main():
     t0 = time.perf_counter()
     for s in range(K):
         step(s)
-    if world > 1:
+    if use_dist:
         dist.all_gather(parts, out)                 # the one exchange: final TB gather over RCCL/xGMI
     torch.cuda.synchronize()
     barrier()
@@ -122,7 +146,7 @@ def main():
     ctx.set_timing(False)
 
     elapsed = torch.tensor([t1 - t0], dtype=torch.float64, device=dev)
-    if world > 1:
+    if use_dist:
         dist.all_reduce(elapsed, op=dist.ReduceOp.MAX)
     elapsed = float(elapsed.item())
 
@@ -172,7 +196,7 @@ def main():
             res["parity_check"] = {"max_abs_dev_K": float(np.abs(tb_gpu[:n] - tb_cpu).max()), "profiles": n,
                                    "against": "oracle/lbl_oracle.c (parity vs pyrtlib unpinned)"}
         print(json.dumps(res), flush=True)
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 
