@@ -81,6 +81,26 @@ __device__ __forceinline__ double fdiv1(double x, double d) {
 // back into (vector) registers across the line loop.
 #define LDS_RELOAD_FENCE() asm volatile("" ::: "memory")
 
+// "Far" lines: every frequency of the chunk is at least FAR_MIN_GHZ (+ the shift allowance) away
+// from the line centre, so D1*D2 may be formed as a polynomial in f^2 without harmful cancellation.
+constexpr double FAR_MIN_GHZ = 0.2;
+constexpr double FAR_SHIFT_GHZ = 0.05;     // O2: |dnu| allowance, checked per line by wave vote
+constexpr double FAR_H2O_GHZ = 5.0;        // H2O: covers any pressure shift (< 1 GHz) with margin
+
+// one bit per line, identical in every wave: lane k tests line k against the nfc chunk frequencies
+__device__ __forceinline__ unsigned long long far_line_mask(const double* sfq, int nslots, int nlines,
+                                                            const __attribute__((address_space(4))) double* centre,
+                                                            double margin, int lane) {
+  bool far = false;
+  if (lane < nlines) {
+    const double c = centre[lane];
+    double dmin = 1e300;
+    for (int j = 0; j < nslots; ++j) dmin = fmin(dmin, fabs(sfq[2 * j] - c));
+    far = dmin >= margin;
+  }
+  return __ballot(far);
+}
+
 struct cplx { double re, im; };
 __device__ __forceinline__ cplx cmul(cplx a, cplx b) { return {a.re * b.re - a.im * b.im, a.re * b.im + a.im * b.re}; }
 __device__ __forceinline__ cplx cadd(cplx a, double r) { return {a.re + r, a.im}; }
@@ -207,7 +227,7 @@ __device__ __forceinline__ H2OLine h2o_line(cmodel M, int k, double pda, double 
 
 template <int NFC>
 __device__ __forceinline__ void h2o_absorb(cmodel M, const LevelState& L, const double* sfq /*LDS: {f, f^2} per slot*/,
-                                           double (&awet)[NFC]) {
+                                           unsigned far_h2o, double (&awet)[NFC]) {
   const double t = L.t;
   const double pvap = fdiv(L.rho * t, M->h2o_pvap_div);
   const double pda = L.p - pvap;
@@ -245,7 +265,21 @@ __device__ __forceinline__ void h2o_absorb(cmodel M, const LevelState& L, const 
     const bool all_res = !sd_line && __all(d1_in && d2_out);
     const bool all_none = !sd_line && __all(d1_out && d2_out);
     LDS_RELOAD_FENCE();
-    if (all_both) {
+    if (all_both && ((far_h2o >> k) & 1u)) {
+      bsum = __builtin_fma(2.0, q.sbase, bsum);
+      const double cc = __builtin_fma(q.c1, q.c1, q.wsq);
+      const double A2 = 2.0 * __builtin_fma(-q.c1, q.c1, q.wsq);
+      const double Bc = cc * cc;
+      const double C2 = 2.0 * cc;
+#pragma unroll
+      for (int j = 0; j < NFC; ++j) {
+        const double f2 = sfq[2 * j + 1];
+        const double den12 = __builtin_fma(f2, f2 + A2, Bc);          // D1 D2
+        double r = __builtin_amdgcn_rcp(den12);
+        r = __builtin_fma(r, __builtin_fma(-den12, r, 1.0), r);
+        sum[j] = __builtin_fma(__builtin_fma(2.0, f2, C2) * r, q.sw, sum[j]);   // D1 + D2 = 2 f^2 + 2 (c^2 + w^2)
+      }
+    } else if (all_both) {
       bsum = __builtin_fma(2.0, q.sbase, bsum);
 #pragma unroll
       for (int j = 0; j < NFC; ++j) {
@@ -333,7 +367,7 @@ __device__ __forceinline__ void h2o_absorb(cmodel M, const LevelState& L, const 
 // ---------------------------------------------------------------------------------------------
 template <int NFC>
 __device__ __forceinline__ void dry_absorb(cmodel M, const LevelState& L, const double* sfq /*LDS: {f, f^2} per slot*/,
-                                           double (&adry)[NFC]) {
+                                           unsigned long long far_o2, double (&adry)[NFC]) {
   const double temp = L.t;
   const double pres = L.p;
   const double th = fdiv(300.0, temp);
@@ -359,6 +393,7 @@ __device__ __forceinline__ void dry_absorb(cmodel M, const LevelState& L, const 
   // (D1, D2 are still formed from d1, d2 directly: no cancellation next to a line centre).
   const int nl = (MWRT_ABLATE & 1) ? 0 : M->n_o2;
   double be_prev = -1.0, ebe = 1.0;
+
   for (int k = 0; k < nl; ++k) {
     const double fk = M->o2_f[k];
     const double y = ymul * (M->o2_y0[k] + M->o2_y1[k] * th1);
@@ -378,17 +413,33 @@ __device__ __forceinline__ void dry_absorb(cmodel M, const LevelState& L, const 
     const double P = 2.0 * (a + cb);
     const double Q = 2.0 * __builtin_fma(c1, c1, df2) * (a - cb);
     LDS_RELOAD_FENCE();
+    if (((far_o2 >> k) & 1ull) && __all(fabs(dnu) < FAR_SHIFT_GHZ)) {
+      // every frequency of the chunk is >= FAR_MIN_GHZ from this line for every lane:
+      //   D1 D2 = f^4 + 2 (w^2 - c^2) f^2 + (c^2 + w^2)^2   (cancellation <= f^2 / (4 FAR_MIN^2) ulp ~ 2e-12)
+      const double cc = __builtin_fma(c1, c1, df2);
+      const double A2 = 2.0 * __builtin_fma(-c1, c1, df2);
+      const double Bc = cc * cc;
 #pragma unroll
-    for (int j = 0; j < NFC; ++j) {
-      const double f = sfq[2 * j], f2 = sfq[2 * j + 1];
-      const double d1 = f - c1;
-      const double d2 = f + c1;
-      const double D1 = __builtin_fma(d1, d1, df2);
-      const double D2 = __builtin_fma(d2, d2, df2);
-      const double den12 = D1 * D2;
-      double r = __builtin_amdgcn_rcp(den12);
-      r = __builtin_fma(r, __builtin_fma(-den12, r, 1.0), r);
-      sum[j] = __builtin_fma(__builtin_fma(f2, P, Q), r, sum[j]);
+      for (int j = 0; j < NFC; ++j) {
+        const double f2 = sfq[2 * j + 1];
+        const double den12 = __builtin_fma(f2, f2 + A2, Bc);
+        double r = __builtin_amdgcn_rcp(den12);
+        r = __builtin_fma(r, __builtin_fma(-den12, r, 1.0), r);
+        sum[j] = __builtin_fma(__builtin_fma(f2, P, Q), r, sum[j]);
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < NFC; ++j) {
+        const double f = sfq[2 * j], f2 = sfq[2 * j + 1];
+        const double d1 = f - c1;
+        const double d2 = f + c1;
+        const double D1 = __builtin_fma(d1, d1, df2);
+        const double D2 = __builtin_fma(d2, d2, df2);
+        const double den12 = D1 * D2;
+        double r = __builtin_amdgcn_rcp(den12);
+        r = __builtin_fma(r, __builtin_fma(-den12, r, 1.0), r);
+        sum[j] = __builtin_fma(__builtin_fma(f2, P, Q), r, sum[j]);
+      }
     }
   }
   const double scale = M->o2_coef * presda * th * th * th;
@@ -508,8 +559,10 @@ k_tb_fused(const FusedArgs A) {
   {
     const double e = goff_gratch_e(ti, rhi);
     const LevelState L = level_state(pi, ti, e);
-    h2o_absorb<NFC>(M, L, sfq, awet);
-    dry_absorb<NFC>(M, L, sfq, adry);
+    const unsigned long long far_o2 = far_line_mask(sfq, NFC, M->n_o2, M->o2_f, FAR_MIN_GHZ + FAR_SHIFT_GHZ, lane);
+    const unsigned far_h2o = (unsigned)far_line_mask(sfq, NFC, M->n_h2o, M->h2o_fl, FAR_H2O_GHZ, lane);
+    h2o_absorb<NFC>(M, L, sfq, far_h2o, awet);
+    dry_absorb<NFC>(M, L, sfq, far_o2, adry);
   }
   // neighbour level i-1: lane-1 through the crossbar, wave seams through a 2*NFC-double edge row
   if (lane == WAVE - 1) {
@@ -964,8 +1017,11 @@ k_absorb(const AbsorbArgs A) {
   double awet[NFC], adry[NFC];
   const double e = goff_gratch_e(ti, rhi);
   const LevelState L = level_state(pi, ti, e);
-  h2o_absorb<NFC>(M, L, sfq, awet);
-  dry_absorb<NFC>(M, L, sfq, adry);
+  const int lane = tid & (WAVE - 1);
+  const unsigned long long far_o2 = far_line_mask(sfq, NFC, M->n_o2, M->o2_f, FAR_MIN_GHZ + FAR_SHIFT_GHZ, lane);
+  const unsigned far_h2o = (unsigned)far_line_mask(sfq, NFC, M->n_h2o, M->h2o_fl, FAR_H2O_GHZ, lane);
+  h2o_absorb<NFC>(M, L, sfq, far_h2o, awet);
+  dry_absorb<NFC>(M, L, sfq, far_o2, adry);
   if (active) {
 #pragma unroll
     for (int j = 0; j < NFC; ++j) {

@@ -271,7 +271,8 @@ def test_fine_grid_config5_shape(gpu_ctx):
     assert v_s.tolist() == [1, 1, 1, 1, 0, 1] and v_f.tolist() == v_s.tolist()
     assert np.isnan(tb_s[4]).all() and np.isnan(tb_f[4]).all()
     keep = [0, 1, 2, 3, 5]
-    assert np.abs(tb_s[keep] - tb_f[keep]).max() <= 1e-9
+    # the fused kernel forms D1*D2 as a polynomial in f^2 for lines >= 0.25 GHz away (<= ~2e-12 relative)
+    assert np.abs(tb_s[keep] - tb_f[keep]).max() <= 1e-8
     sub = np.arange(0, 1000, 37)
     m = sp.get_model("R24")
     r = c_oracle.tb_profile(m, P["z"][1], P["p"][1], P["t"][1], P["rh"][1], frq[sub], ang)
