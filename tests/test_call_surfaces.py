@@ -1,0 +1,88 @@
+"""The two other call surfaces the north star names (run_pyrtlib, rttov-gb wrapper), on CPU with the
+oracle injected through the engine seam."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import oracle_engine
+from mwr_fast_forward_operators_and_lbls_amd import profiles as pr, spectroscopy as sp
+from mwr_fast_forward_operators_and_lbls_amd import rttov_gb_wrapper as rw, run_pyrtlib as rp
+from oracle import lbl_oracle as lo
+
+
+def rttov_text(nprof=3, nlev=30, elevs=(90.0, 30.0, 90.0)):
+    P = pr.synthetic_profiles(nprof, 51, nlev=nlev)
+    text = ""
+    for i in range(nprof):
+        p, t, rh = P["p"][i][::-1], P["t"][i][::-1], P["rh"][i][::-1]           # top -> ground
+        ppmv = 1e6 * rh * rw.goff_gratch_es(t) / p
+        text += rw.write1profile2str(t, ppmv, nlev, p, np.zeros(nlev), height_in_km=P["z"][i][0], deg_lat=50.9,
+                                     zenith_angle=90.0 - elevs[i])
+    return text, P
+
+
+def test_profile_text_roundtrip_matches_reference_format():
+    text, P = rttov_text()
+    lines = text.splitlines()
+    assert len(lines) == 3 * (4 * 30 + 3)
+    assert len(lines[0]) == 8 and len(lines[30]) == 7 and len(lines[60]) >= 9 and "E" in lines[90]
+    profs = rw.parse_profiles(text, 30)
+    assert len(profs) == 3 and profs[1]["zenith"] == 60.0 and abs(profs[0]["lat"] - 50.9) < 1e-9
+    assert np.allclose(profs[2]["p"], P["p"][2][::-1], atol=5e-5)
+    assert np.allclose(profs[2]["t"], P["t"][2][::-1], atol=5e-4)
+    with pytest.raises(ValueError):
+        rw.parse_profiles(text + "1.0\n", 30)
+
+
+def test_batch_creator_edges():
+    assert [list(r) for r in rw.batch_creator(list(range(45)), 20)] == [list(range(0, 20)), list(range(20, 40)),
+                                                                          list(range(40, 45))]
+    assert [list(r) for r in rw.batch_creator(list(range(41)), 20)] == [list(range(0, 20)), list(range(20, 41))]
+    assert list(rw.batch_creator([1], 20)) == []
+
+
+def test_simulate_and_output_blocks():
+    text, P = rttov_text()
+    profs = rw.parse_profiles(text, 30)
+    res = rw.simulate(profs, "R24", _engine=oracle_engine)
+    assert res["tbs"].shape == (3, 14) and res["tau_levels"].shape == (3, 30, 14) and (res["valid"] == 1).all()
+    # hydrostatic heights + ppmv round trip reproduce the direct LBL run to well under the text precision
+    z, p, t, rh, elev = rw.to_lbl_inputs(profs)
+    ref = lo.tb_cloud_rte(sp.get_model("R24"), z[1], p[1], t[1], rh[1], rw.HATPRO_FRQS, np.array([30.0]))
+    assert np.allclose(res["tbs"][1], ref["tbtotal"], atol=1e-9)
+    assert np.allclose(res["tau_total"][1], np.exp(-(ref["tauwet"] + ref["taudry"])), rtol=1e-12)
+    assert np.allclose(z[0], P["z"][0], atol=0.25)                    # rebuilt geometry ~ generator's
+    assert np.allclose(res["tau_levels"][:, -1, :], 1.0)              # ground level: nothing below it
+    assert np.allclose(res["tau_levels"][:, 0, :], res["tau_total"])  # top level: whole path
+    assert (np.diff(res["tau_levels"], axis=1) >= 0).all()            # transmittance grows towards the ground
+    txt = rw.format_output(res)
+    assert txt.count("CALCULATED BRIGHTNESS TEMPERATURES (K):") == 3
+    tbs, trans, levels = rw.parse_output(txt, 30)
+    assert np.allclose(tbs, res["tbs"], atol=5e-3) and np.allclose(trans, res["tau_total"], atol=5e-5)
+    assert levels.shape == (3, 30, 14) and np.allclose(levels, res["tau_levels"], atol=5e-5)
+
+
+def test_run_pyrtlib_surface(tmp_path, capsys):
+    P = pr.synthetic_profiles(2, 52, nlev=24)
+    good = tmp_path / "20240821_123404.npz"
+    np.savez(good, z=P["z"][0], p=P["p"][0], t=P["t"][0], rh=P["rh"][0],
+             z_crop=P["z"][1], p_crop=P["p"][1], t_crop=P["t"][1], rh_crop=P["rh"][1])
+    bad = tmp_path / "20240822_000000.npz"
+    t_nan = P["t"][0].copy(); t_nan[3] = np.nan
+    np.savez(bad, z=P["z"][0], p=P["p"][0], t=t_nan, rh=P["rh"][0])
+    done = rp.main(["-i", str(tmp_path) + os.sep, "-p", "20*.npz"], _engine=oracle_engine)
+    out = capsys.readouterr().out
+    assert len(done) == 1 and "Could not process radiosonde" in out
+    col = np.genfromtxt(done[0], skip_header=1)
+    assert col.shape == (252,)
+    order = rp.LEGACY_MODEL_ORDER
+    r24_uncropped = col[126 + 14 * order.index("R24"):126 + 14 * order.index("R24") + 14]
+    r98_cropped = col[14 * order.index("R98"):14 * order.index("R98") + 14]
+    ref = lo.tb_cloud_rte(sp.get_model("R24"), P["z"][0], P["p"][0], P["t"][0], P["rh"][0], rp.HATPRO_FRQS, np.array([90.0]))
+    assert np.allclose(r24_uncropped, ref["tbtotal"], atol=1e-9)
+    ref = lo.tb_cloud_rte(sp.get_model("R98"), P["z"][1], P["p"][1], P["t"][1], P["rh"][1], rp.HATPRO_FRQS, np.array([90.0]))
+    assert np.allclose(r98_cropped, ref["tbtotal"], atol=1e-9)
+    assert np.isnan(col[14:28]).all()                                  # R03: no tables in this build
+    args = rp.parse_arguments(["-s", "whatever.py"])
+    assert args.script == "whatever.py" and args.pattern == "20*.npz"

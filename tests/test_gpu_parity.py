@@ -309,3 +309,45 @@ def test_spectral_level_chunks(gpu_ctx, nlev):
     r = c_oracle.tb_profile(sp.get_model("R20"), P["z"][1], P["p"][1], P["t"][1], P["rh"][1], frq, ang)
     assert (valid == 1).all()
     assert np.abs(tb[1] - r["tbtotal"].reshape(2, 70)).max() <= TOL_K
+
+
+def test_rttov_gb_style_surface_on_gpu(gpu_ctx):
+    from conftest import oracle_engine
+    from test_call_surfaces import rttov_text
+    from mwr_fast_forward_operators_and_lbls_amd import rttov_gb_wrapper as rw
+    text, _ = rttov_text(nprof=5, nlev=180, elevs=(90.0, 30.0, 90.0, 4.2, 30.0))
+    profs = rw.parse_profiles(text, 180)
+    got = rw.simulate(profs, "R24")
+    ref = rw.simulate(profs, "R24", _engine=oracle_engine)
+    assert (got["valid"] == 1).all()
+    assert np.abs(got["tbs"] - ref["tbs"]).max() <= TOL_K
+    assert np.allclose(got["tau_total"], ref["tau_total"], rtol=1e-9, atol=1e-300)
+    assert np.allclose(got["tau_levels"], ref["tau_levels"], rtol=1e-9, atol=1e-300)
+
+
+def test_run_pyrtlib_surface_on_gpu(gpu_ctx, tmp_path):
+    from mwr_fast_forward_operators_and_lbls_amd import run_pyrtlib as rp
+    P = pr.synthetic_profiles(1, 53)
+    f = tmp_path / "20240101_000000.npz"
+    np.savez(f, z=P["z"][0], p=P["p"][0], t=P["t"][0], rh=P["rh"][0])
+    done = rp.main(["-i", str(tmp_path) + os.sep])
+    col = np.genfromtxt(done[0], skip_header=1)
+    k = rp.LEGACY_MODEL_ORDER.index("R17")
+    ref = lo.tb_cloud_rte(sp.get_model("R17"), P["z"][0], P["p"][0], P["t"][0], P["rh"][0], pr.HATPRO_FRQS, np.array([90.0]))
+    assert np.abs(col[126 + 14 * k:126 + 14 * k + 14] - ref["tbtotal"]).max() <= TOL_K
+    assert np.array_equal(col[:126][~np.isnan(col[:126])], col[126:][~np.isnan(col[126:])])   # no crop variants given
+
+
+def test_config4_shape_with_nan_fraction(gpu_ctx):
+    """BASELINE config 4 per-GPU share (1250 profiles x 14 x 7) with 0.5 % NaN-poisoned profiles:
+    flags, NaN rows and untouched neighbours, checked against a clean run bitwise."""
+    P = pr.synthetic_profiles(1250, 4, nan_fraction=0.005)
+    C = pr.synthetic_profiles(1250, 4)
+    bad = np.zeros(1250, bool)
+    for k in ("z", "p", "t", "rh"):
+        bad |= np.isnan(P[k]).any(axis=1)
+    assert 1 <= bad.sum() <= 20
+    tb, valid = gpu_ctx.tb_batch("R24", P["z"], P["p"], P["t"], P["rh"], pr.HATPRO_FRQS, pr.BENCH_ELEVATIONS_7)
+    tc, vc = gpu_ctx.tb_batch("R24", C["z"], C["p"], C["t"], C["rh"], pr.HATPRO_FRQS, pr.BENCH_ELEVATIONS_7)
+    assert np.array_equal(valid == 0, bad) and (vc == 1).all()
+    assert np.isnan(tb[bad]).all() and np.array_equal(tb[~bad], tc[~bad])
