@@ -56,7 +56,7 @@ typedef struct mwrt_model_desc {
   int32_t n_h2o, n_o2;
   int32_t h2o_shift_mode;   /* 0 none (R98); 2 air+self shift with ln-T coefficients (R17+) */
   int32_t o2_mix_mode;      /* 0 first order on total pressure (R98/R17); 1 second order on den (R19+) */
-  int32_t o2_line1_dens;    /* R98: 118.75-GHz width uses DENS */
+  int32_t o2_line1_dens;    /* R98: 118.75-GHz width uses DENS (first-order mixing mode only) */
   int32_t n2_fdep;          /* absn2 frequency-dependence factor on/off */
   int32_t n2_ptot;          /* 1: N2 at total pressure (pre-2019, folded into the O2 routine) */
   int32_t reserved0;

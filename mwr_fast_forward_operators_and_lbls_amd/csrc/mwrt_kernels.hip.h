@@ -433,7 +433,7 @@ __device__ __forceinline__ void dry_absorb(cmodel M, const LevelState& L, const 
       dnu = pe2 * (M->o2_dnu0[k] + M->o2_dnu1[k] * th1);
       gfac = 1.0 + pe2 * (M->o2_g0[k] + M->o2_g1[k] * th1);
     }
-    const double df = M->o2_w300[k] * ((k == 0 && M->o2_line1_dens) ? dens : den);
+    const double df = M->o2_w300[k] * ((k == 0 && !second && M->o2_line1_dens) ? dens : den);
     const double be = M->o2_be[k];
     if (be != be_prev) { ebe = fexp(-be * th1); be_prev = be; }     // N- / N+ partners share BE (uniform branch)
     const double str = M->o2_s300[k] * ebe * M->o2_rf2[k];           // * f^2 at the end
@@ -854,7 +854,7 @@ k_tb_spectral(const SpectralArgs A) {
           dnu = o[SPO_PE2] * (M->o2_dnu0[k] + M->o2_dnu1[k] * th1);
           gfac = 1.0 + o[SPO_PE2] * (M->o2_g0[k] + M->o2_g1[k] * th1);
         }
-        const double df = M->o2_w300[k] * ((k == 0 && M->o2_line1_dens) ? o[SPO_DENS] : den);
+        const double df = M->o2_w300[k] * ((k == 0 && !second && M->o2_line1_dens) ? o[SPO_DENS] : den);
         const double str = M->o2_s300[k] * fexp(-M->o2_be[k] * th1) * M->o2_rf2[k];
         const double c1 = M->o2_f[k] + dnu;
         const double df2 = df * df;

@@ -351,3 +351,56 @@ def test_config4_shape_with_nan_fraction(gpu_ctx):
     tc, vc = gpu_ctx.tb_batch("R24", C["z"], C["p"], C["t"], C["rh"], pr.HATPRO_FRQS, pr.BENCH_ELEVATIONS_7)
     assert np.array_equal(valid == 0, bad) and (vc == 1).all()
     assert np.isnan(tb[bad]).all() and np.array_equal(tb[~bad], tc[~bad])
+
+
+@pytest.mark.parametrize("seed", [0, 1, 2, 3])
+def test_fuzzed_tables_and_switches(gpu_ctx, seed):
+    """Randomly perturbed line tables and randomly flipped model switches: every code path the
+    switches select (shift modes, mixing modes, 118-GHz exception, N2 variants, SD on any line,
+    exponents that are zero / non-zero) must track the oracle, not just the five shipped models."""
+    import dataclasses
+    rng = np.random.default_rng(100 + seed)
+    base = sp.get_model(["R98", "R17", "R20SD", "R24"][seed])
+
+    def jig(a, rel=0.05):
+        return np.asarray(a) * (1.0 + rel * rng.uniform(-1, 1, np.shape(a)))
+
+    h2o = {k: jig(v) for k, v in base.h2o.items()}
+    o2 = {k: jig(v) for k, v in base.o2.items()}
+    n = len(h2o["fl"])
+    h2o["fl"], o2["f"] = base.h2o["fl"].copy(), base.o2["f"].copy()        # keep centres: cutoffs stay meaningful
+    sdl = rng.integers(0, n, 2)                                           # speed dependence on two random lines
+    for k in ("w2", "w2s"):
+        h2o[k] = np.zeros(n); h2o[k][sdl] = {"w2": 0.4e-3, "w2s": 1.6e-3}[k] * rng.uniform(0.5, 1.5, 2)
+    h2o["xw2"] = rng.uniform(0.3, 1.0, n); h2o["xw2s"] = rng.uniform(0.3, 1.3, n)
+    h2o["d2"] = np.zeros(n); h2o["d2"][sdl] = rng.uniform(-2e-5, 2e-5, 2)
+    h2o["d2s"] = np.zeros(n); h2o["d2s"][sdl] = rng.uniform(-2e-4, 2e-4, 2)
+    h2o["aair"] = rng.uniform(0, 1, n) * (rng.random(n) < 0.3)
+    h2o["aself"] = rng.uniform(0, 10, n) * (rng.random(n) < 0.3)
+    h2o["xh"] = rng.uniform(0, 2.5, n) * (rng.random(n) < 0.5)
+    h2o["xhs"] = rng.uniform(0, 1.0, n) * (rng.random(n) < 0.5)
+    h2o["sh"] = rng.uniform(-2e-4, 2e-4, n); h2o["shs"] = rng.uniform(-1.5e-3, 1.5e-3, n)
+    mix = int(rng.integers(0, 2))
+    if mix:
+        m = len(o2["f"])
+        o2["g0"] = rng.uniform(-0.3, 0.2, m); o2["g1"] = rng.uniform(-0.6, 0.2, m)
+        o2["dnu0"] = rng.uniform(-0.05, 0.05, m); o2["dnu1"] = rng.uniform(-0.03, 0.03, m)
+    tab = dataclasses.replace(
+        base, name=f"fuzz{seed}", h2o=h2o, o2=o2,
+        h2o_shift_mode=int(rng.choice([0, 2])), o2_mix_mode=mix, o2_line1_dens=int(rng.integers(0, 2)),
+        n2_fdep=int(rng.integers(0, 2)), n2_ptot=int(rng.integers(0, 2)),
+        o2_x=float(rng.uniform(0.7, 0.85)), o2_wv_factor=float(rng.uniform(1.0, 1.3)),
+        h2o_reftline=float(rng.choice([296.0, 300.0])), t_cosmic=float(rng.uniform(2.6, 2.8)))
+    P = pr.synthetic_profiles(3, 60 + seed, nlev=90)
+    frq = np.concatenate([pr.HATPRO_FRQS, [h2o["fl"][sdl[0]] + 0.3, 183.0, 2.5, 89.0]])
+    ang = np.array([90.0, 12.0, 4.2])
+    for policy in (1, 2):
+        gpu_ctx.set_kernel_policy(policy)
+        try:
+            tb, valid = gpu_ctx.tb_batch(tab, P["z"], P["p"], P["t"], P["rh"], frq, ang)
+        finally:
+            gpu_ctx.set_kernel_policy(0)
+        assert (valid == 1).all()
+        for i in (0, 2):
+            ref = lo.tb_cloud_rte(tab, P["z"][i], P["p"][i], P["t"][i], P["rh"][i], frq, ang)["tbtotal"]
+            assert np.abs(tb[i].ravel() - ref).max() <= TOL_K, (policy, i)

@@ -139,3 +139,20 @@ def test_pyrtlib_row_order_is_angle_major():
     a = lo.tb_cloud_rte(m, P["z"][0], P["p"][0], P["t"][0], P["rh"][0], f, np.array([90.0]))["tbtotal"]
     b = lo.tb_cloud_rte(m, P["z"][0], P["p"][0], P["t"][0], P["rh"][0], f, np.array([10.0]))["tbtotal"]
     assert np.array_equal(both[:3], a) and np.array_equal(both[3:], b)
+
+
+def test_textbook_absorption_anchors():
+    """Sea-level absorption (1013.25 hPa, 288.15 K, 7.5 g/m3) against the textbook values every
+    MPM-family model reproduces: ~15 dB/km at the 60-GHz O2 complex, ~1.3-1.7 dB/km at 118.75 GHz,
+    ~0.17-0.19 dB/km at the 22.235-GHz H2O line, ~27-30 dB/km at 183.31 GHz."""
+    p, t = np.array([1013.25]), np.array([288.15])
+    e = 7.5 * 461.5e-5 * 288.15
+    rh = e / lo.vapor(t, np.array([1.0]))[0]
+    f = np.array([22.235, 60.0, 118.75, 183.31])
+    for name in MODELS:
+        aw, ad = lo.absorption_profile(sp.get_model(name), p, t, rh, f)
+        wet, dry = aw[:, 0] * 4.343, ad[:, 0] * 4.343
+        assert 0.165 < wet[0] < 0.19, (name, wet[0])
+        assert 27.0 < wet[3] < 30.0, (name, wet[3])
+        assert 14.0 < dry[1] < 15.5, (name, dry[1])
+        assert 1.25 < dry[2] < 1.7, (name, dry[2])
