@@ -54,10 +54,20 @@ def cpu_baseline(tables, P, frq, ang, budget_s=20.0):
     c_oracle.tb_batch(tables, P["z"], P["p"], P["t"], P["rh"], frq, ang, nthreads=cores)
     dtn = time.perf_counter() - t0
     ev = len(frq) * len(ang)
+    # the reference's own cost structure in its own language: one solver call per (profile, angle),
+    # Python loops over angles and frequencies, NumPy over levels (oracle/lbl_oracle.py)
+    from oracle import lbl_oracle
+    npy = min(4, P["z"].shape[0])
+    t0 = time.perf_counter()
+    for i in range(npy):
+        lbl_oracle.tb_cloud_rte(tables, P["z"][i], P["p"][i], P["t"][i], P["rh"][i], frq, ang)
+    dtp = time.perf_counter() - t0
     return {"value": n * ev / dt1, "unit": "TB evaluations/s", "cores": 1, "kind": "port",
             "sample": f"{n} of the {P['z'].shape[0]} profiles x {len(frq)} ch x {len(ang)} elev, oracle/lbl_oracle.c "
                       f"(pyrtlib loop order), {dt1:.1f} s on 1 core",
-            "all_cores": {"value": P["z"].shape[0] * ev / dtn, "cores": cores, "seconds": round(dtn, 2)}}, tb, n
+            "all_cores": {"value": P["z"].shape[0] * ev / dtn, "cores": cores, "seconds": round(dtn, 2)},
+            "pyrtlib_shaped_numpy": {"value": npy * ev / dtp, "cores": 1, "profiles": npy,
+                                     "what": "oracle/lbl_oracle.py, pyrtlib's loop structure in NumPy"}}, tb, n
 
 
 class _stdout_to_stderr:
