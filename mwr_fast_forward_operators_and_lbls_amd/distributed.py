@@ -44,12 +44,14 @@ def gather_shards(local, nprof_total: int, group=None):
     return torch.cat(parts, dim=0)[:nprof_total]
 
 
-def tb_batch_sharded(model, z, p, t, rh, frq, ang, group=None, device_id: Optional[int] = None, _engine=None):
+def tb_batch_sharded(model, z, p, t, rh, frq, ang, group=None, device_id: Optional[int] = None,
+                     gather_device=None):
     """Evaluate a GLOBAL batch (same arrays on every rank) across the ranks of ``group``.
 
     Each rank computes its contiguous block with the HIP library on its own GPU and the blocks
     are gathered once.  Returns ``(tb [nprof][nang][nf], valid [nprof])`` as NumPy arrays on
-    every rank.  ``_engine`` is the CPU test seam (gloo tests inject the oracle)."""
+    every rank.  ``gather_device`` is where the result shards sit for the collective: the rank's
+    GPU (default; RCCL needs device tensors) or ``torch.device("cpu")`` under the gloo backend."""
     import torch
     import torch.distributed as dist
 
@@ -60,21 +62,14 @@ def tb_batch_sharded(model, z, p, t, rh, frq, ang, group=None, device_id: Option
     frq = np.asarray(frq, dtype=np.float64)
     ang = np.asarray(ang, dtype=np.float64)
     nf, nang = len(frq), len(ang)
-    use_gpu = _engine is None
-    dev = torch.device("cuda", device_id if device_id is not None else torch.cuda.current_device()) if use_gpu \
-        else torch.device("cpu")
+    from . import _native
+    if device_id is None:
+        device_id = torch.cuda.current_device() if gather_device is None else 0
+    dev = gather_device if gather_device is not None else torch.device("cuda", device_id)
     if hi > lo:
         sl = slice(lo, hi)
-        if use_gpu:
-            from ._native import default_context
-            tb, valid = default_context(dev.index).tb_batch(model, z[sl], np.asarray(p)[sl], np.asarray(t)[sl],
-                                                            np.asarray(rh)[sl], frq, ang)
-        else:
-            from . import spectroscopy
-            tables = spectroscopy.get_model(model) if isinstance(model, str) else model
-            tb, valid, _ = _engine(tables, np.ascontiguousarray(z[sl]), np.ascontiguousarray(np.asarray(p)[sl]),
-                                   np.ascontiguousarray(np.asarray(t)[sl]), np.ascontiguousarray(np.asarray(rh)[sl]),
-                                   frq, ang)
+        tb, valid = _native.default_context(device_id).tb_batch(model, z[sl], np.asarray(p)[sl], np.asarray(t)[sl],
+                                                                np.asarray(rh)[sl], frq, ang)
     else:
         tb = np.empty((0, nang, nf))
         valid = np.empty(0, dtype=np.uint8)

@@ -20,7 +20,7 @@ import os
 
 import numpy as np
 
-from ._native import default_context
+from . import _native
 from .dataset import Dataset
 from . import spectroscopy
 
@@ -87,9 +87,9 @@ def _attrs(tag):
     }
 
 
-def derive_TBs4PyRTlib(ds, args=None, _engine=None):
-    """Reference :83-197.  ``_engine`` is a test seam (tests inject the CPU oracle to exercise the
-    packing logic without a GPU); the default engine is the HIP library and nothing else."""
+def derive_TBs4PyRTlib(ds, args=None):
+    """Reference :83-197.  Every model run goes to the HIP library (one batched call per model);
+    there is no other engine."""
     frqs = np.array([22.24, 23.04, 23.84, 25.44, 26.24, 27.84, 31.4, 51.26, 52.28,
                      53.86, 54.94, 56.66, 57.3, 58.])
     nf = len(frqs)
@@ -101,10 +101,7 @@ def derive_TBs4PyRTlib(ds, args=None, _engine=None):
     results = {}
     for suffix, mdl in MODEL_RUNS:
         tables = spectroscopy.get_model(mdl)
-        if _engine is not None:
-            tb, valid, _ = _engine(tables, z, p, t, rh, frqs, ang)
-        else:
-            tb, valid = default_context().tb_batch(tables, z, p, t, rh, frqs, ang)
+        tb, valid = _native.default_context().tb_batch(tables, z, p, t, rh, frqs, ang)
         bad = np.nonzero(valid == 2)[0]
         if bad.size:     # the reference does not catch pyrtlib's exception (:123-127)
             raise ValueError("Error encountered in exponential_integration "

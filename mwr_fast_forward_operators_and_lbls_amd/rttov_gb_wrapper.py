@@ -24,7 +24,7 @@ from typing import Iterable, List
 import numpy as np
 
 from . import spectroscopy
-from ._native import default_context
+from . import _native
 
 HATPRO_FRQS = np.array([22.24, 23.04, 23.84, 25.44, 26.24, 27.84, 31.4, 51.26, 52.28,
                         53.86, 54.94, 56.66, 57.3, 58.])
@@ -102,7 +102,7 @@ def to_lbl_inputs(profiles: Iterable[dict]):
     return (np.array(Z), np.array(P), np.array(T), np.array(RH), np.array(ELEV))
 
 
-def simulate(profiles: List[dict], model: str = "R24", frqs=HATPRO_FRQS, _engine=None):
+def simulate(profiles: List[dict], model: str = "R24", frqs=HATPRO_FRQS):
     """TBs, surface-to-space transmittance and level-to-surface transmittances for parsed profiles.
 
     Returns dict: ``tbs`` [nprof][nchan], ``tau_total`` [nprof][nchan] (transmittance, slant path),
@@ -118,10 +118,7 @@ def simulate(profiles: List[dict], model: str = "R24", frqs=HATPRO_FRQS, _engine
     for ang in np.unique(elev):                             # profiles sharing an elevation go in one launch
         idx = np.nonzero(elev == ang)[0]
         args = (tables, z[idx], p[idx], t[idx], rh[idx], np.asarray(frqs, dtype=float), np.array([ang]))
-        if _engine is not None:
-            tb, v, ex = _engine(*args)
-        else:
-            tb, v, ex = default_context().tb_batch(*args, extras=True)
+        tb, v, ex = _native.default_context().tb_batch(*args, extras=True)
         am = 1.0 / np.sin(ang * np.pi / 180)
         lay = ex["taulay"] * am                              # [n][nf][nlev] slant layer optical depth, ground -> top
         cum = np.cumsum(lay, axis=2)                         # surface -> level i

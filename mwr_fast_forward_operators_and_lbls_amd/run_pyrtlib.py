@@ -22,7 +22,7 @@ import os
 import numpy as np
 
 from . import spectroscopy
-from ._native import default_context
+from . import _native
 
 LEGACY_MODEL_ORDER = ["R17", "R03", "R16", "R19", "R98", "R19SD", "R20", "R20SD", "R24"]   # old_merge2nc.py:417-435
 HATPRO_FRQS = np.array([22.24, 23.04, 23.84, 25.44, 26.24, 27.84, 31.4, 51.26, 52.28,
@@ -39,7 +39,7 @@ def parse_arguments(argv=None):
     return parser.parse_args(argv)
 
 
-def process_file(path: str, _engine=None) -> str:
+def process_file(path: str) -> str:
     """One file -> ``<path>_out.txt`` with the legacy 252-row ``tbtotal`` column."""
     with np.load(path, allow_pickle=False) as f:
         prof = {k: np.asarray(f[k], dtype=np.float64) for k in f.files}
@@ -56,10 +56,7 @@ def process_file(path: str, _engine=None) -> str:
                 rows.append(np.full(14, np.nan))
                 continue
             tables = spectroscopy.get_model(mdl)
-            if _engine is not None:
-                tb, valid, _ = _engine(tables, z, p, t, rh, HATPRO_FRQS, ang)
-            else:
-                tb, valid = default_context().tb_batch(tables, z, p, t, rh, HATPRO_FRQS, ang)
+            tb, valid = _native.default_context().tb_batch(tables, z, p, t, rh, HATPRO_FRQS, ang)
             if valid[0] != 1:
                 raise ValueError(f"profile rejected (valid={int(valid[0])})")
             rows.append(tb[0, 0])
@@ -71,7 +68,7 @@ def process_file(path: str, _engine=None) -> str:
     return out
 
 
-def main(argv=None, _engine=None):
+def main(argv=None):
     args = parse_arguments(argv)
     files_in = sorted(glob.glob(args.input + args.pattern))
     print("\n\nStart processing of all files via the LBL operator: ")
@@ -79,7 +76,7 @@ def main(argv=None, _engine=None):
     for i, file in enumerate(files_in):
         print(i, file)
         try:
-            done.append(process_file(file, _engine=_engine))
+            done.append(process_file(file))
         except Exception:                                      # reference :53-57 swallows every failure
             print("Could not process radiosonde: ", file)
             continue

@@ -27,7 +27,7 @@ from typing import Optional
 import numpy as np
 
 from . import spectroscopy
-from ._native import default_context
+from . import _native
 
 DATAFRAME_COLUMNS = ["tbtotal", "tbatm", "tmr", "tmrcld", "tauwet", "taudry", "tauliq", "tauice"]
 
@@ -56,7 +56,6 @@ class TbCloudRTE(object):
         self.cloudy = cloudy
         self._absmdl = absmdl
         self._tables = None
-        self._engine = None          # test seam only; None = the HIP library, no fallback
         if absmdl:
             self.init_absmdl(absmdl)
 
@@ -101,10 +100,7 @@ class TbCloudRTE(object):
             raise NotImplementedError("ozone profile (o3n) is outside the hot path")
 
         z, p, t, rh = (np.ascontiguousarray(a, dtype=np.float64)[None, :] for a in (self.z, self.p, self.tk, self.rh))
-        if self._engine is not None:
-            tb, valid, ex = self._engine(self._tables, z, p, t, rh, self.frq, self.angles)
-        else:
-            tb, valid, ex = default_context().tb_batch(self._tables, z, p, t, rh, self.frq, self.angles, extras=True)
+        tb, valid, ex = _native.default_context().tb_batch(self._tables, z, p, t, rh, self.frq, self.angles, extras=True)
         if valid[0] == 2:
             # pyrtlib raises inside RTEquation.exponential_integration on negative absorption
             raise ValueError("Error encountered in exponential_integration")

@@ -30,8 +30,31 @@ def gpu_ctx(native_lib):
     ctx.close()
 
 
+class OracleContext:
+    """Stands in for ``_native.Context`` in CPU-only host-logic tests: same ``tb_batch`` signature,
+    numbers from the oracle.  Installed by the ``oracle_ctx`` fixture through monkeypatching
+    ``_native.default_context`` -- the product code itself has no alternative engine."""
+
+    def tb_batch(self, model, z, p, t, rh, frq, elev, extras=False):
+        import numpy as np
+        from mwr_fast_forward_operators_and_lbls_amd import spectroscopy
+        tables = spectroscopy.get_model(model) if isinstance(model, str) else model
+        tb, valid, ex = oracle_engine(tables, np.ascontiguousarray(z, dtype=float), np.ascontiguousarray(p, dtype=float),
+                                      np.ascontiguousarray(t, dtype=float), np.ascontiguousarray(rh, dtype=float),
+                                      np.asarray(frq, dtype=float).ravel(), np.asarray(elev, dtype=float).ravel())
+        return (tb, valid, ex) if extras else (tb, valid)
+
+
+@pytest.fixture
+def oracle_ctx(monkeypatch):
+    from mwr_fast_forward_operators_and_lbls_amd import _native
+    ctx = OracleContext()
+    monkeypatch.setattr(_native, "default_context", lambda device_id=0: ctx)
+    return ctx
+
+
 def oracle_engine(tables, z, p, t, rh, frq, ang):
-    """Test seam for host-logic tests on CPU: the oracle behind the engine signature."""
+    """The oracle behind the batch signature (profiles [nprof][nlev] -> tb, valid, extras)."""
     import numpy as np
     from oracle import lbl_oracle
     nprof = z.shape[0]

@@ -1,11 +1,10 @@
-"""The two other call surfaces the north star names (run_pyrtlib, rttov-gb wrapper), on CPU with the
-oracle injected through the engine seam."""
+"""The two other call surfaces the north star names (run_pyrtlib, rttov-gb wrapper), on CPU with
+`_native.default_context` monkeypatched to the oracle-backed stand-in (`oracle_ctx` fixture)."""
 import os
 
 import numpy as np
 import pytest
 
-from conftest import oracle_engine
 from mwr_fast_forward_operators_and_lbls_amd import profiles as pr, spectroscopy as sp
 from mwr_fast_forward_operators_and_lbls_amd import rttov_gb_wrapper as rw, run_pyrtlib as rp
 from oracle import lbl_oracle as lo
@@ -42,10 +41,10 @@ def test_batch_creator_edges():
     assert list(rw.batch_creator([1], 20)) == []
 
 
-def test_simulate_and_output_blocks():
+def test_simulate_and_output_blocks(oracle_ctx):
     text, P = rttov_text()
     profs = rw.parse_profiles(text, 30)
-    res = rw.simulate(profs, "R24", _engine=oracle_engine)
+    res = rw.simulate(profs, "R24")
     assert res["tbs"].shape == (3, 14) and res["tau_levels"].shape == (3, 30, 14) and (res["valid"] == 1).all()
     # hydrostatic heights + ppmv round trip reproduce the direct LBL run to well under the text precision
     z, p, t, rh, elev = rw.to_lbl_inputs(profs)
@@ -63,7 +62,7 @@ def test_simulate_and_output_blocks():
     assert levels.shape == (3, 30, 14) and np.allclose(levels, res["tau_levels"], atol=5e-5)
 
 
-def test_run_pyrtlib_surface(tmp_path, capsys):
+def test_run_pyrtlib_surface(tmp_path, capsys, oracle_ctx):
     P = pr.synthetic_profiles(2, 52, nlev=24)
     good = tmp_path / "20240821_123404.npz"
     np.savez(good, z=P["z"][0], p=P["p"][0], t=P["t"][0], rh=P["rh"][0],
@@ -71,7 +70,7 @@ def test_run_pyrtlib_surface(tmp_path, capsys):
     bad = tmp_path / "20240822_000000.npz"
     t_nan = P["t"][0].copy(); t_nan[3] = np.nan
     np.savez(bad, z=P["z"][0], p=P["p"][0], t=t_nan, rh=P["rh"][0])
-    done = rp.main(["-i", str(tmp_path) + os.sep, "-p", "20*.npz"], _engine=oracle_engine)
+    done = rp.main(["-i", str(tmp_path) + os.sep, "-p", "20*.npz"])
     out = capsys.readouterr().out
     assert len(done) == 1 and "Could not process radiosonde" in out
     col = np.genfromtxt(done[0], skip_header=1)

@@ -1,4 +1,5 @@
-"""N>1 path on CPU: world_size-2 gloo processes, oracle injected as the engine."""
+"""N>1 path on CPU: world_size-2 gloo processes; each worker monkeypatches
+`_native.default_context` with the oracle-backed stand-in (no GPU here)."""
 import os
 import socket
 import sys
@@ -26,17 +27,20 @@ def test_shard_bounds_cover_exactly():
 def _worker(rank, world, port, nprof, q):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import torch
     import torch.distributed as dist
-    from conftest import oracle_engine
-    from mwr_fast_forward_operators_and_lbls_amd import profiles as pr
+    from conftest import OracleContext
+    from mwr_fast_forward_operators_and_lbls_amd import profiles as pr, _native
     from mwr_fast_forward_operators_and_lbls_amd.distributed import tb_batch_sharded
+    ctx = OracleContext()
+    _native.default_context = lambda device_id=0: ctx
     dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
     try:
         P = pr.synthetic_profiles(nprof, 33, nlev=24)
         if nprof > 1:
             P["rh"][1, 2] = np.nan
         tb, valid = tb_batch_sharded("R98", P["z"], P["p"], P["t"], P["rh"], pr.HATPRO_FRQS[:3],
-                                     np.array([90.0, 10.0]), _engine=oracle_engine)
+                                     np.array([90.0, 10.0]), gather_device=torch.device("cpu"))
         q.put((rank, tb, valid))
     finally:
         dist.destroy_process_group()

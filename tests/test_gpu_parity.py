@@ -217,14 +217,17 @@ def test_reference_call_surface_end_to_end(gpu_ctx):
             assert np.abs(df_from_ground["tbtotal"].values - ref).max() <= TOL_K
 
 
-def test_wrapper_end_to_end(gpu_ctx):
+def test_wrapper_end_to_end(gpu_ctx, monkeypatch):
     from test_host_logic import make_ds
-    from conftest import oracle_engine
-    from mwr_fast_forward_operators_and_lbls_amd import pyrtlib_processing as pp
+    from conftest import OracleContext
+    from mwr_fast_forward_operators_and_lbls_amd import pyrtlib_processing as pp, _native
     ds, _ = make_ds(ntime=3, ncrop=2, nlev=180, elev=tuple(pr.REFERENCE_ELEVATIONS), nan_at=(7, 2, 1))
     ds2, _ = make_ds(ntime=3, ncrop=2, nlev=180, elev=tuple(pr.REFERENCE_ELEVATIONS), nan_at=(7, 2, 1))
-    out = pp.derive_TBs4PyRTlib(ds, None)
-    ref = pp.derive_TBs4PyRTlib(ds2, None, _engine=oracle_engine)
+    out = pp.derive_TBs4PyRTlib(ds, None)                       # HIP library
+    octx = OracleContext()
+    monkeypatch.setattr(_native, "default_context", lambda device_id=0: octx)
+    ref = pp.derive_TBs4PyRTlib(ds2, None)                      # same host code over the oracle
+    monkeypatch.undo()
     for tag in ("R24", "R17", "R98", "R20"):
         a, b = out["TBs_PyRTlib_" + tag].values, ref["TBs_PyRTlib_" + tag].values
         assert a.shape == (3, 14, 10, 2)
@@ -311,14 +314,17 @@ def test_spectral_level_chunks(gpu_ctx, nlev):
     assert np.abs(tb[1] - r["tbtotal"].reshape(2, 70)).max() <= TOL_K
 
 
-def test_rttov_gb_style_surface_on_gpu(gpu_ctx):
-    from conftest import oracle_engine
+def test_rttov_gb_style_surface_on_gpu(gpu_ctx, monkeypatch):
+    from conftest import OracleContext
     from test_call_surfaces import rttov_text
-    from mwr_fast_forward_operators_and_lbls_amd import rttov_gb_wrapper as rw
+    from mwr_fast_forward_operators_and_lbls_amd import rttov_gb_wrapper as rw, _native
     text, _ = rttov_text(nprof=5, nlev=180, elevs=(90.0, 30.0, 90.0, 4.2, 30.0))
     profs = rw.parse_profiles(text, 180)
     got = rw.simulate(profs, "R24")
-    ref = rw.simulate(profs, "R24", _engine=oracle_engine)
+    octx = OracleContext()
+    monkeypatch.setattr(_native, "default_context", lambda device_id=0: octx)
+    ref = rw.simulate(profs, "R24")
+    monkeypatch.undo()
     assert (got["valid"] == 1).all()
     assert np.abs(got["tbs"] - ref["tbs"]).max() <= TOL_K
     assert np.allclose(got["tau_total"], ref["tau_total"], rtol=1e-9, atol=1e-300)

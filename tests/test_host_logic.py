@@ -1,9 +1,9 @@
-"""Host-side mirror of the reference call surface, exercised on CPU with the oracle injected
-through the `_engine` test seam (the product default is the HIP library, no fallback)."""
+"""Host-side mirror of the reference call surface, exercised on CPU: the `oracle_ctx` fixture
+monkeypatches `_native.default_context` with an oracle-backed stand-in (the product code has no
+alternative engine and no fallback)."""
 import numpy as np
 import pytest
 
-from conftest import oracle_engine
 from mwr_fast_forward_operators_and_lbls_amd import profiles as pr, spectroscopy as sp
 from mwr_fast_forward_operators_and_lbls_amd import pyrtlib_processing as pp
 from mwr_fast_forward_operators_and_lbls_amd.dataset import Dataset
@@ -42,11 +42,11 @@ def test_pack_profiles_reverses_and_converts():
     assert z.flags.c_contiguous and (np.diff(z, axis=1) > 0).all()
 
 
-def test_derive_tbs_matches_reference_loop_semantics():
+def test_derive_tbs_matches_reference_loop_semantics(oracle_ctx):
     """Batched wrapper == what the reference's triple loop (PyRTlib_processing.py:99-151) produces:
     one TbCloudRTE per (time, Crop, elevation), output slot [i, :, k, j]."""
     ds, _ = make_ds(ntime=2, ncrop=2, nlev=30, elev=(90.0, 8.4))
-    out = pp.derive_TBs4PyRTlib(ds, None, _engine=oracle_engine)
+    out = pp.derive_TBs4PyRTlib(ds, None)
     frqs = pr.HATPRO_FRQS
     for tag in ("R24", "R17", "R98", "R20"):
         var = out["TBs_PyRTlib_" + tag]
@@ -66,9 +66,9 @@ def test_derive_tbs_matches_reference_loop_semantics():
                     assert np.allclose(var.values[i, :, k, j], ref, rtol=0, atol=1e-9)
 
 
-def test_derive_tbs_nan_profile_stays_nan(capsys):
+def test_derive_tbs_nan_profile_stays_nan(capsys, oracle_ctx):
     ds, _ = make_ds(ntime=2, ncrop=2, nlev=30, elev=(90.0,), nan_at=(5, 1, 0))
-    out = pp.derive_TBs4PyRTlib(ds, None, _engine=oracle_engine)
+    out = pp.derive_TBs4PyRTlib(ds, None)
     v = out["TBs_PyRTlib_R24"].values
     assert np.isnan(v[1, :, :, 0]).all()
     assert not np.isnan(v[0]).any() and not np.isnan(v[1, :, :, 1]).any()
@@ -96,7 +96,7 @@ def test_dataset_npz_roundtrip(tmp_path):
     assert back["Level_z"].attrs == {"units": "m"}
 
 
-def test_tbcloudrte_shim_surface():
+def test_tbcloudrte_shim_surface(oracle_ctx, monkeypatch):
     P = pr.synthetic_profiles(1, 5, nlev=30)
     z, p, t, rh = (P[k][0] for k in ("z", "p", "t", "rh"))
     frq, ang = pr.HATPRO_FRQS[:4], np.array([90.0, 30.0])
@@ -111,7 +111,6 @@ def test_tbcloudrte_shim_surface():
     with pytest.raises(NotImplementedError):
         rte.execute()                        # satellite=True (pyrtlib's default) is out of scope
     rte.satellite = False
-    rte._engine = oracle_engine
     df = rte.execute()
     assert list(df.columns) == DATAFRAME_COLUMNS and len(df) == 8
     ref = lo.tb_cloud_rte(sp.get_model("R24"), z, p, t, rh, frq, ang)
@@ -126,7 +125,7 @@ def test_tbcloudrte_shim_surface():
         rte.init_cloudy(None, None, None)
 
 
-def test_tbcloudrte_negative_absorption_raises_like_pyrtlib():
+def test_tbcloudrte_negative_absorption_raises_like_pyrtlib(oracle_ctx):
     P = pr.synthetic_profiles(1, 5, nlev=30)
     z, p, t, rh = (P[k][0] for k in ("z", "p", "t", "rh"))
     # negative rh only zeroes the wet term (rho <= 0 branch); a negative absorption needs hostile
@@ -135,7 +134,7 @@ def test_tbcloudrte_negative_absorption_raises_like_pyrtlib():
     bad = dataclasses.replace(sp.get_model("R98"), name="R98_negcont", h2o_cf=-1e-6)
     sp.register_model(bad, overwrite=True)
     rte = TbCloudRTE(z, p, t, rh, pr.HATPRO_FRQS[:2], np.array([90.0]))
-    rte.init_absmdl("R98_negcont"); rte.satellite = False; rte._engine = oracle_engine
+    rte.init_absmdl("R98_negcont"); rte.satellite = False
     with pytest.raises(ValueError, match="exponential_integration"):
         rte.execute()
 
@@ -154,9 +153,9 @@ def test_model_tables_json_roundtrip_and_registry():
         sp.register_model(custom)
 
 
-def test_netcdf3_roundtrip_and_cli_io(tmp_path):
+def test_netcdf3_roundtrip_and_cli_io(tmp_path, oracle_ctx):
     ds, _ = make_ds(ntime=2, ncrop=2, nlev=20, elev=(90.0, 30.0))
-    out = pp.derive_TBs4PyRTlib(ds, None, _engine=oracle_engine)
+    out = pp.derive_TBs4PyRTlib(ds, None)
     path = str(tmp_path / "tbs.nc")
     pp.write_dataset(out, path)
     with open(path, "rb") as fh:
