@@ -129,6 +129,40 @@ def simulate(profiles: List[dict], model: str = "R24", frqs=HATPRO_FRQS):
     return {"tbs": tbs, "tau_total": trans, "tau_levels": trans_lev, "valid": valid}
 
 
+def jacobians(profile: dict, model: str = "R24", frqs=HATPRO_FRQS, dT: float = 0.05, rel_q: float = 0.01):
+    """Brute-force K-matrix of one profile by central differences through the batched operator.
+
+    RTTOV-gb's K run (the block the reference parses at RTTOV_gb_processing.py:264-283) returns
+    dTB/dx per level; a tangent-linear kernel does not exist yet, but one launch over the
+    ``4*nlev`` perturbed copies of the profile costs about as much as one profile.  Heights are
+    rebuilt hydrostatically for every perturbed copy (as RTTOV-gb does internally).
+
+    Returns ``(dTB_dT [nlev][nchan] in K/K, dTB_dq [nlev][nchan] in K/ppmv)``, levels TOP -> GROUND.
+    """
+    nlev = len(profile["p"])
+    copies = []
+    for sign in (+1.0, -1.0):
+        for lv in range(nlev):
+            c = dict(profile)
+            c["t"] = profile["t"].copy()
+            c["t"][lv] += sign * dT
+            copies.append(c)
+    for sign in (+1.0, -1.0):
+        for lv in range(nlev):
+            c = dict(profile)
+            c["ppmv"] = profile["ppmv"].copy()
+            c["ppmv"][lv] *= (1.0 + sign * rel_q)
+            copies.append(c)
+    res = simulate(copies, model, frqs)
+    if not (res["valid"] == 1).all():
+        raise ValueError("a perturbed profile was rejected")
+    tb = res["tbs"]
+    d_t = (tb[0:nlev] - tb[nlev:2 * nlev]) / (2.0 * dT)
+    dq = 2.0 * rel_q * profile["ppmv"][:, None]
+    d_q = (tb[2 * nlev:3 * nlev] - tb[3 * nlev:4 * nlev]) / np.where(dq != 0.0, dq, np.nan)
+    return d_t, d_q
+
+
 def format_output(result: dict) -> str:
     """Text with the markers the reference's parser keys on (RTTOV_gb_processing.py:225-262)."""
     out = []

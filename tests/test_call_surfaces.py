@@ -85,3 +85,25 @@ def test_run_pyrtlib_surface(tmp_path, capsys, oracle_ctx):
     assert np.isnan(col[14:28]).all()                                  # R03: no tables in this build
     args = rp.parse_arguments(["-s", "whatever.py"])
     assert args.script == "whatever.py" and args.pattern == "20*.npz"
+
+
+def test_finite_difference_jacobians(oracle_ctx):
+    text, _ = rttov_text(nprof=1, nlev=24, elevs=(90.0,))
+    prof = rw.parse_profiles(text, 24)[0]
+    d_t, d_q = rw.jacobians(prof, "R98")
+    assert d_t.shape == (24, 14) and d_q.shape == (24, 14)
+    # an opaque channel reads the air temperature: its temperature weights sum to ~1 and sit near the ground
+    assert abs(d_t[:, 13].sum() - 1.0) < 0.03 and d_t[-6:, 13].sum() > 0.8
+    # a window channel barely sees temperature but warms with water vapour everywhere below the tropopause
+    assert abs(d_t[:, 6].sum()) < 0.2 and (d_q[-12:, 0] > 0).all()
+    # one entry against a direct oracle difference
+    z, p, t, rh, elev = rw.to_lbl_inputs([prof])
+    lv = 20
+    pp_, pm = dict(prof), dict(prof)
+    pp_["t"] = prof["t"].copy(); pp_["t"][lv] += 0.05
+    pm["t"] = prof["t"].copy(); pm["t"][lv] -= 0.05
+    tbs = []
+    for q in (pp_, pm):
+        z, p, t, rh, _ = rw.to_lbl_inputs([q])
+        tbs.append(lo.tb_cloud_rte(sp.get_model("R98"), z[0], p[0], t[0], rh[0], rw.HATPRO_FRQS, np.array([90.0]))["tbtotal"])
+    assert np.allclose(d_t[lv], (tbs[0] - tbs[1]) / 0.1, atol=1e-8)
