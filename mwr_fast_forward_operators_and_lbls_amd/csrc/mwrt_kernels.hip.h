@@ -230,7 +230,7 @@ __device__ __forceinline__ double goff_gratch_e(double tk, double rh) {
   const double LN10 = 2.302585092994045684;
   const double INV_LN10 = 0.434294481903251828;
   double y = 373.16 / tk;
-  double es = -7.90298 * (y - 1.0) + 5.02808 * (log(y) * INV_LN10)
+  double es = -7.90298 * (y - 1.0) + 5.02808 * (flog(y) * INV_LN10)
             - 1.3816e-07 * (fexp(LN10 * (11.344 * (1.0 - (1.0 / y)))) - 1.0)
             + 0.0081328 * (fexp(LN10 * (-3.49149 * (y - 1.0))) - 1.0) + 3.0057148979490314 /*log10(1013.246)*/;
   return rh * fexp(LN10 * es);
@@ -298,10 +298,10 @@ __device__ __forceinline__ void h2o_absorb(cmodel M, const LevelState& L, const 
   const double pvap = fdiv(L.rho * t, M->h2o_pvap_div);
   const double pda = L.p - pvap;
   const double den = M->h2o_den_coef * L.rho;
-  const double lnc = log(fdiv(M->h2o_reftcon, t));
+  const double lnc = flog(fdiv(M->h2o_reftcon, t));
   const double con0 = (M->h2o_cf * pda * fexp(M->h2o_xcf * lnc) + M->h2o_cs * pvap * fexp(M->h2o_xcs * lnc)) * pvap;
   const double ti = fdiv(M->h2o_reftline, t);
-  const double tiln = log(ti);
+  const double tiln = flog(ti);
   const double ti2 = fexp(2.5 * tiln);
   const bool shifted = M->h2o_shift_mode != 0;
   double sum[NFC];
@@ -438,7 +438,7 @@ __device__ __forceinline__ void dry_absorb(cmodel M, const LevelState& L, const 
   const double pres = L.p;
   const double th = fdiv(300.0, temp);
   const double th1 = th - 1.0;
-  const double lnth = log(th);
+  const double lnth = flog(th);
   const double b = fexp(M->o2_x * lnth);
   const double preswv = fdiv(L.rho * temp, M->o2_pvap_div);
   const double presda = pres - preswv;
@@ -746,9 +746,9 @@ k_tb_fused(const FusedArgs A) {
         boftotl = B; boftmr = B;
       }
       const int64_t o = (prof * nang + a) * A.nf + jbase + j;
-      A.tb[o] = fdiv(hvk, log(1.0 + fdiv(1.0, boftotl)));
-      if (A.tbatm) A.tbatm[o] = fdiv(hvk, log(1.0 + fdiv(1.0, B)));
-      if (A.tmr) A.tmr[o] = fdiv(hvk, log(1.0 + fdiv(1.0, boftmr)));
+      A.tb[o] = fdiv(hvk, flog(1.0 + fdiv(1.0, boftotl)));
+      if (A.tbatm) A.tbatm[o] = fdiv(hvk, flog(1.0 + fdiv(1.0, B)));
+      if (A.tmr) A.tmr[o] = fdiv(hvk, flog(1.0 + fdiv(1.0, boftmr)));
       if (want_tau) {
         const double am = cam[a];
         double sw = 0.0, sd = 0.0;
@@ -848,13 +848,13 @@ k_tb_spectral(const SpectralArgs A) {
       // H2O preamble
       const double pvap = fdiv(L.rho * L.t, M->h2o_pvap_div);
       const double pda = L.p - pvap;
-      const double lnc = log(fdiv(M->h2o_reftcon, L.t));
+      const double lnc = flog(fdiv(M->h2o_reftcon, L.t));
       const double con0 = (M->h2o_cf * pda * fexp(M->h2o_xcf * lnc) + M->h2o_cs * pvap * fexp(M->h2o_xcs * lnc)) * pvap;
       const double ti = fdiv(M->h2o_reftline, L.t);
-      const double tiln = log(ti);
+      const double tiln = flog(ti);
       // O2 preamble
       const double th = fdiv(300.0, L.t);
-      const double lnth = log(th);
+      const double lnth = flog(th);
       const double b = fexp(M->o2_x * lnth);
       const double preswv = fdiv(L.rho * L.t, M->o2_pvap_div);
       const double presda = L.p - preswv;
@@ -1038,9 +1038,9 @@ k_tb_spectral(const SpectralArgs A) {
           boftotl = __builtin_fma(bbg, ex, Bt[a]);
           boftmr = fdiv(Bt[a], 1.0 - ex);
         } else { boftotl = Bt[a]; boftmr = Bt[a]; }
-        tbv = fdiv(hvk, log(1.0 + fdiv(1.0, boftotl)));
-        tbatm = fdiv(hvk, log(1.0 + fdiv(1.0, Bt[a])));
-        tmr = fdiv(hvk, log(1.0 + fdiv(1.0, boftmr)));
+        tbv = fdiv(hvk, flog(1.0 + fdiv(1.0, boftotl)));
+        tbatm = fdiv(hvk, flog(1.0 + fdiv(1.0, Bt[a])));
+        tmr = fdiv(hvk, flog(1.0 + fdiv(1.0, boftmr)));
       }
       A.tb[o] = tbv;
       if (A.tbatm) A.tbatm[o] = tbatm;
