@@ -1,6 +1,6 @@
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-import numpy as np, torch
+import torch
 from mwr_fast_forward_operators_and_lbls_amd import _native as nat, profiles as pr
 ctx = nat.Context(0); dev = torch.device("cuda:0")
 frq = pr.fine_grid_frequencies(1000); ang = pr.BENCH_ELEVATIONS_7

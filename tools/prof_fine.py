@@ -1,6 +1,6 @@
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-import numpy as np, torch
+import torch
 from mwr_fast_forward_operators_and_lbls_amd import _native as nat, profiles as pr
 pol = int(sys.argv[1]); nprof = int(sys.argv[2]) if len(sys.argv) > 2 else 100
 ctx = nat.Context(0); dev = torch.device("cuda:0")
