@@ -19,7 +19,8 @@
  *              after the wrapper's [::-1] (:123); z in km, p in hPa, T in K, rh as fraction
  *              (:109-114).
  *   frq_ghz    [nf]    (:87-88)
- *   elev_deg   [nang]  ELEVATION angles, 90 = zenith (:106, :37)
+ *   elev_deg   [nang]  ELEVATION angles in (0, 180), 90 = zenith (:106, :37); the path is
+ *              plane-parallel (air mass 1/sin elev), other values are MWRT_ERR_INVALID_ARGUMENT
  *   tb_out     [nprof][nang][nf]  == pyrtlib's DataFrame row order (angle-major) per profile
  *   valid_out  [nprof] 1 = ok; 0 = NaN in the inputs of that profile (the wrapper's
  *              check_for_nans, :71-79, :117-119: outputs stay NaN); 2 = negative absorption

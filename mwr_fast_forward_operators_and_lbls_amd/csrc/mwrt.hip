@@ -337,7 +337,12 @@ int mwrt_tb_batch_device(mwrt_context* c, const mwrt_model* m, int64_t nprof, in
     return MWRT_OK;
   }
   std::vector<double> am(nang);
-  for (int a = 0; a < nang; ++a) am[a] = 1.0 / std::sin(elev[a] * M_PI / 180.0);   // plane-parallel air mass
+  for (int a = 0; a < nang; ++a) {
+    // plane-parallel air mass 1/sin(elev); a path at or below the horizon has none
+    if (!(elev[a] > 0.0 && elev[a] < 180.0))
+      return fail(MWRT_ERR_INVALID_ARGUMENT, "elevation angles must lie in (0, 180) degrees");
+    am[a] = 1.0 / std::sin(elev[a] * M_PI / 180.0);
+  }
   rc = upload_small(c, c->d_frq, c->h_frq, frq, nf, st); if (rc) return rc;
   rc = upload_small(c, c->d_am, c->h_am, am.data(), nang, st); if (rc) return rc;
 

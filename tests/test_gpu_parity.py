@@ -447,3 +447,24 @@ def test_jacobians_on_gpu(gpu_ctx):
     assert d_t.shape == (180, 14) and np.isfinite(d_t).all() and np.isfinite(d_q).all()
     assert abs(d_t[:, 13].sum() - 1.0) < 0.03                  # 58 GHz: temperature weights integrate to one
     assert (d_q[-60:, 0] > 0).all()                            # 22.24 GHz warms with boundary-layer humidity
+
+
+def test_argument_validation(gpu_ctx):
+    import ctypes
+    from mwr_fast_forward_operators_and_lbls_amd._native import MwrtError
+    P = pr.synthetic_profiles(2, 72, nlev=30)
+    for bad in (0.0, -5.0, 180.0, 270.0):
+        with pytest.raises(MwrtError) as ei:
+            gpu_ctx.tb_batch("R24", P["z"], P["p"], P["t"], P["rh"], pr.HATPRO_FRQS, np.array([90.0, bad]))
+        assert ei.value.code == -1 and "elevation" in str(ei.value)
+    tb, _ = gpu_ctx.tb_batch("R24", P["z"], P["p"], P["t"], P["rh"], pr.HATPRO_FRQS, np.array([30.0, 150.0]))
+    assert np.allclose(tb[:, 0], tb[:, 1], rtol=0, atol=1e-9)           # sin(150 deg) = sin(30 deg)
+    with pytest.raises(ValueError):
+        gpu_ctx.tb_batch("R24", P["z"], P["p"][:, :-1], P["t"], P["rh"], pr.HATPRO_FRQS, np.array([90.0]))
+    lib = gpu_ctx._lib
+    desc = sp.get_model("R24").to_c()
+    desc.n_o2 = 65
+    h = ctypes.c_void_p()
+    assert lib.mwrt_model_create(gpu_ctx._handle, ctypes.byref(desc), ctypes.byref(h)) == -1
+    assert lib.mwrt_tb_batch(gpu_ctx._handle, None, 1, 30, None, None, None, None, 14, None, 1, None, None, None, None) == -1
+    assert lib.mwrt_set_kernel_policy(gpu_ctx._handle, 7) == -1
