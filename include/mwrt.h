@@ -145,6 +145,11 @@ int mwrt_absorption_batch_device(mwrt_context* ctx, const mwrt_model* model,
  * Results agree to rounding; this exists for tests and measurements. */
 int mwrt_set_kernel_policy(mwrt_context* ctx, int policy);
 
+/* Diagnostic: evaluates the kernels' own exp / log / division helpers (fexp, flog, fdiv, fdiv1) on
+ * host arrays x[n], y_pos[n] (y > 0), so their accuracy can be checked against libm. */
+int mwrt_selftest_math(mwrt_context* ctx, int32_t n, const double* x, const double* y_pos,
+                       double* exp_x, double* log_y, double* x_div_y, double* x_div1_y);
+
 /* Block until everything queued on the context's stream (or `stream`) has finished. */
 int mwrt_synchronize(mwrt_context* ctx, void* stream);
 

@@ -53,6 +53,7 @@ SIGNATURES = {
     "mwrt_absorption_batch": (ctypes.c_int, [_vp, _vp, _i64, _i32, _vp, _vp, _vp, _i32, _vp, _vp, _vp]),
     "mwrt_absorption_batch_device": (ctypes.c_int, [_vp, _vp, _i64, _i32, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp]),
     "mwrt_set_kernel_policy": (ctypes.c_int, [_vp, ctypes.c_int]),
+    "mwrt_selftest_math": (ctypes.c_int, [_vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp]),
     "mwrt_synchronize": (ctypes.c_int, [_vp, _vp]),
     "mwrt_set_timing": (ctypes.c_int, [_vp, ctypes.c_int]),
     "mwrt_timing_collect": (ctypes.c_int, [_vp, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int32)]),
@@ -238,6 +239,14 @@ class Context:
     def set_kernel_policy(self, policy: int):
         """0 auto, 1 always the lane=level fused kernel, 2 always the lane=frequency spectral kernel."""
         self._check(self._lib.mwrt_set_kernel_policy(self._handle, int(policy)), "mwrt_set_kernel_policy")
+
+    def selftest_math(self, x, y_pos):
+        """(fexp(x), flog(y), fdiv(x, y), fdiv1(x, y)) as evaluated by the device helpers."""
+        x, y = _f64(x).ravel(), _f64(y_pos).ravel()
+        outs = [np.empty_like(x) for _ in range(4)]
+        self._check(self._lib.mwrt_selftest_math(self._handle, x.size, _ptr(x), _ptr(y), *[_ptr(o) for o in outs]),
+                    "mwrt_selftest_math")
+        return outs
 
     def synchronize(self, stream: int = 0):
         self._check(self._lib.mwrt_synchronize(self._handle, ctypes.c_void_p(stream) if stream else None),

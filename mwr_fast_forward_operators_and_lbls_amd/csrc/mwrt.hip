@@ -480,6 +480,28 @@ int mwrt_set_kernel_policy(mwrt_context* c, int policy) {
   return MWRT_OK;
 }
 
+int mwrt_selftest_math(mwrt_context* c, int32_t n, const double* x, const double* y_pos,
+                       double* exp_x, double* log_y, double* x_div_y, double* x_div1_y) {
+  if (!c || n < 0 || !x || !y_pos || !exp_x || !log_y || !x_div_y || !x_div1_y)
+    return fail(MWRT_ERR_INVALID_ARGUMENT, "null argument");
+  if (n == 0) return MWRT_OK;
+  HIP_TRY(hipSetDevice(c->device));
+  const size_t b = sizeof(double) * (size_t)n;
+  HIP_TRY(c->d_in.reserve(2 * b));
+  HIP_TRY(c->d_out.reserve(4 * b));
+  double* din = c->d_in.as<double>();
+  double* dout = c->d_out.as<double>();
+  HIP_TRY(hipMemcpyAsync(din, x, b, hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(hipMemcpyAsync(din + n, y_pos, b, hipMemcpyHostToDevice, c->stream));
+  hipLaunchKernelGGL(k_selftest_math, dim3((n + 255) / 256), dim3(256), 0, c->stream, din, din + n, dout, dout + n,
+                     dout + 2 * (size_t)n, dout + 3 * (size_t)n, n);
+  HIP_TRY(hipGetLastError());
+  double* dst[4] = {exp_x, log_y, x_div_y, x_div1_y};
+  for (int k = 0; k < 4; ++k) HIP_TRY(hipMemcpyAsync(dst[k], dout + (size_t)k * n, b, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  return MWRT_OK;
+}
+
 int mwrt_synchronize(mwrt_context* c, void* stream) {
   if (!c) return fail(MWRT_ERR_INVALID_ARGUMENT, "null context");
   HIP_TRY(hipSetDevice(c->device));

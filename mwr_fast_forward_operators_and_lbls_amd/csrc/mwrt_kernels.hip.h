@@ -1,9 +1,9 @@
 // mwrt_kernels.hip.h -- hand-written gfx950 (CDNA4) kernels of the LBL forward operator.
 //
-// Mapping (DESIGN.md section 3): one workgroup = one (profile, frequency-chunk); one LANE = one LEVEL
-// of that profile.  Line tables and frequencies are wave-uniform, so they travel through the
-// scalar unit (s_load) and every per-(level,line) transcendental is evaluated once per lane and
-// reused for the NFC frequencies of the chunk.  Phase K1 leaves zenith layer optical depths and
+// Mapping (DESIGN.md section 4): one workgroup = one (profile, frequency-chunk); one LANE = one LEVEL
+// of that profile.  Line tables are wave-uniform and travel through the scalar unit (s_load),
+// the chunk's frequencies are broadcast-read from LDS, and every per-(level,line) transcendental
+// is evaluated once per lane and reused for the NFC frequencies of the chunk.  Phase K1 leaves zenith layer optical depths and
 // Planck functions in LDS; phase K2 integrates the slant-path RTE out of LDS for all
 // (frequency, angle) pairs; nothing but the 4 profile fields and the TBs touches HBM.
 //
@@ -1108,6 +1108,17 @@ k_absorb(const AbsorbArgs A) {
       }
     }
   }
+}
+
+// diagnostic: the local exp / log / division helpers on caller-supplied arguments (mwrt_selftest_math)
+__global__ void k_selftest_math(const double* x, const double* y, double* out_exp, double* out_log, double* out_div,
+                                double* out_div1, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  out_exp[i] = fexp(x[i]);
+  out_log[i] = flog(y[i]);
+  out_div[i] = fdiv(x[i], y[i]);
+  out_div1[i] = fdiv1(x[i], y[i]);
 }
 
 }  // namespace mwrt

@@ -468,3 +468,26 @@ def test_argument_validation(gpu_ctx):
     assert lib.mwrt_model_create(gpu_ctx._handle, ctypes.byref(desc), ctypes.byref(h)) == -1
     assert lib.mwrt_tb_batch(gpu_ctx._handle, None, 1, 30, None, None, None, None, 14, None, 1, None, None, None, None) == -1
     assert lib.mwrt_set_kernel_policy(gpu_ctx._handle, 7) == -1
+
+
+def test_device_math_helpers(gpu_ctx):
+    """fexp / flog / fdiv / fdiv1 against libm over the ranges the kernels use (and their edges)."""
+    rng = np.random.default_rng(5)
+    x = np.concatenate([rng.uniform(-50, 50, 20000), rng.uniform(-745, -600, 2000), rng.uniform(600, 709, 2000),
+                        [0.0, -0.0, 1e-300, -1e-300, -1000.0, -1e6, 709.7]])
+    y = np.concatenate([np.exp(rng.uniform(-30, 30, 20000)), 1.0 + rng.uniform(-1e-6, 1e-6, 4000),
+                        [1.0, 0.5, 2.0, 0.70710678118654752, 1.4142135623730951, 1e-300, 1e300]])
+    n = min(len(x), len(y)); x, y = x[:n], y[:n]
+    ex, lg, dv, dv1 = gpu_ctx.selftest_math(x, y)
+    ref = np.exp(x)
+    ok = ref > 1e-300
+    assert np.abs(ex[ok] / ref[ok] - 1).max() < 5e-16
+    assert (ex[~ok] >= 0).all() and (ex[~ok] < 1e-299).all()            # underflow side: 0 or denormal, never garbage
+    assert ex[np.flatnonzero(x == 0.0)[0]] == 1.0
+    rl = np.log(y)
+    big = np.abs(rl) > 1e-3
+    assert np.abs(lg[big] / rl[big] - 1).max() < 5e-16
+    assert np.abs(lg[~big] - rl[~big]).max() < 1e-21 + 5e-16 * np.abs(rl[~big]).max()   # relative accuracy near 1
+    assert lg[np.flatnonzero(y == 1.0)[0]] == 0.0
+    assert np.abs(dv * y / x - 1)[x != 0].max() < 1e-15
+    assert np.abs(dv1 * y / x - 1)[x != 0].max() < 1e-13
