@@ -46,9 +46,13 @@ def cpu_baseline(tables, P, frq, ang, budget_s=20.0):
     dt = time.perf_counter() - t0
     # scale the single-core sample to ~budget_s/2 of CPU work, capped at the whole batch
     n = int(min(P["z"].shape[0], max(n1, n1 * (budget_s / 2) / max(dt, 1e-6))))
-    t0 = time.perf_counter()
-    tb, _ = c_oracle.tb_batch(tables, P["z"][:n], P["p"][:n], P["t"][:n], P["rh"][:n], frq, ang, nthreads=1)
-    dt1 = time.perf_counter() - t0
+    # ... and repeated until ~budget_s/2 of single-core work has been timed (the whole config-2 batch is only ~2 s)
+    passes, dt1 = 0, 0.0
+    while passes == 0 or (dt1 < budget_s / 2 and passes < 16):
+        t0 = time.perf_counter()
+        tb, _ = c_oracle.tb_batch(tables, P["z"][:n], P["p"][:n], P["t"][:n], P["rh"][:n], frq, ang, nthreads=1)
+        dt1 += time.perf_counter() - t0
+        passes += 1
     cores = os.cpu_count() or 1
     t0 = time.perf_counter()
     c_oracle.tb_batch(tables, P["z"], P["p"], P["t"], P["rh"], frq, ang, nthreads=cores)
@@ -62,9 +66,9 @@ def cpu_baseline(tables, P, frq, ang, budget_s=20.0):
     for i in range(npy):
         lbl_oracle.tb_cloud_rte(tables, P["z"][i], P["p"][i], P["t"][i], P["rh"][i], frq, ang)
     dtp = time.perf_counter() - t0
-    return {"value": n * ev / dt1, "unit": "TB evaluations/s", "cores": 1, "kind": "port",
-            "sample": f"{n} of the {P['z'].shape[0]} profiles x {len(frq)} ch x {len(ang)} elev, oracle/lbl_oracle.c "
-                      f"(pyrtlib loop order), {dt1:.1f} s on 1 core",
+    return {"value": passes * n * ev / dt1, "unit": "TB evaluations/s", "cores": 1, "kind": "port",
+            "sample": f"{passes} pass(es) over {n} of the {P['z'].shape[0]} profiles x {len(frq)} ch x {len(ang)} elev, "
+                      f"oracle/lbl_oracle.c (pyrtlib loop order), {dt1:.1f} s on 1 core",
             "all_cores": {"value": P["z"].shape[0] * ev / dtn, "cores": cores, "seconds": round(dtn, 2)},
             "pyrtlib_shaped_numpy": {"value": npy * ev / dtp, "cores": 1, "profiles": npy,
                                      "what": "oracle/lbl_oracle.py, pyrtlib's loop structure in NumPy"}}, tb, n
