@@ -130,10 +130,23 @@ def _ptr(x):
     return x.ctypes.data_as(ctypes.c_void_p) if isinstance(x, np.ndarray) else ctypes.c_void_p(int(x))
 
 
+def _serialised(method):
+    """A native context owns one workspace and one stream: calls from several Python threads are
+    serialised per context (ctypes drops the GIL during the call)."""
+    import functools
+
+    @functools.wraps(method)
+    def wrapper(self, *args, **kwargs):
+        with self._lock:
+            return method(self, *args, **kwargs)
+    return wrapper
+
+
 class Context:
     """One (host thread, GPU) pair: HIP stream + workspace + cached model tables."""
 
     def __init__(self, device_id: int = 0):
+        self._lock = threading.RLock()
         self._lib = load_library()
         h = ctypes.c_void_p()
         self._handle = None
@@ -148,6 +161,7 @@ class Context:
         if rc != 0:
             raise MwrtError(rc, where, self._lib.mwrt_last_error().decode("utf-8", "replace"))
 
+    @_serialised
     def close(self):
         if getattr(self, "_handle", None):
             for m in self._models.values():
@@ -168,6 +182,7 @@ class Context:
     def __exit__(self, *exc):
         self.close()
 
+    @_serialised
     def model(self, model) -> ctypes.c_void_p:
         """Device-resident tables for a model name or a ModelTables record (cached per context)."""
         tables = get_model(model) if isinstance(model, str) else model
@@ -184,6 +199,7 @@ class Context:
         return h
 
     # -- host-buffer entry points ------------------------------------------------------------
+    @_serialised
     def tb_batch(self, model, z, p, t, rh, frq, elev, extras=False):
         """[nprof][nlev] profiles (ground->top) -> tb [nprof][nang][nf], valid [nprof] (+ extras dict)."""
         z = _f64(z)
@@ -206,6 +222,7 @@ class Context:
             ctypes.byref(exs) if exs is not None else None), "mwrt_tb_batch")
         return (tb, valid, ex) if extras else (tb, valid)
 
+    @_serialised
     def absorption_batch(self, model, p, t, rh, frq):
         """-> awet, adry [nprof][nf][nlev] in Np/km."""
         p = _f64(p)
@@ -220,6 +237,7 @@ class Context:
         return awet, adry
 
     # -- device-buffer entry points (raw device addresses, e.g. torch.Tensor.data_ptr()) -------
+    @_serialised
     def tb_batch_device(self, model, nprof, nlev, d_z, d_p, d_t, d_rh, frq, elev, d_tb, d_valid,
                         extras: Optional[MwrtTbExtras] = None, stream: int = 0):
         frq, elev = _f64(frq).ravel(), _f64(elev).ravel()
@@ -229,6 +247,7 @@ class Context:
             ctypes.byref(extras) if extras is not None else None,
             ctypes.c_void_p(stream) if stream else None), "mwrt_tb_batch_device")
 
+    @_serialised
     def absorption_batch_device(self, model, nprof, nlev, d_p, d_t, d_rh, frq, d_awet, d_adry, stream: int = 0):
         frq = _f64(frq).ravel()
         self._check(self._lib.mwrt_absorption_batch_device(
@@ -236,10 +255,12 @@ class Context:
             frq.size, _ptr(frq), _ptr(d_awet), _ptr(d_adry),
             ctypes.c_void_p(stream) if stream else None), "mwrt_absorption_batch_device")
 
+    @_serialised
     def set_kernel_policy(self, policy: int):
         """0 auto, 1 always the lane=level fused kernel, 2 always the lane=frequency spectral kernel."""
         self._check(self._lib.mwrt_set_kernel_policy(self._handle, int(policy)), "mwrt_set_kernel_policy")
 
+    @_serialised
     def selftest_math(self, x, y_pos):
         """(fexp(x), flog(y), fdiv(x, y), fdiv1(x, y)) as evaluated by the device helpers."""
         x, y = _f64(x).ravel(), _f64(y_pos).ravel()
@@ -248,19 +269,23 @@ class Context:
                     "mwrt_selftest_math")
         return outs
 
+    @_serialised
     def synchronize(self, stream: int = 0):
         self._check(self._lib.mwrt_synchronize(self._handle, ctypes.c_void_p(stream) if stream else None),
                     "mwrt_synchronize")
 
+    @_serialised
     def set_timing(self, enabled: bool):
         self._check(self._lib.mwrt_set_timing(self._handle, int(bool(enabled))), "mwrt_set_timing")
 
+    @_serialised
     def timing_collect(self):
         """(total device ms, number of launches) since timing was enabled / last collected."""
         ms, n = ctypes.c_double(), ctypes.c_int32()
         self._check(self._lib.mwrt_timing_collect(self._handle, ctypes.byref(ms), ctypes.byref(n)), "mwrt_timing_collect")
         return ms.value, n.value
 
+    @_serialised
     def last_kernel_ms(self) -> float:
         ms = ctypes.c_double()
         self._check(self._lib.mwrt_last_kernel_ms(self._handle, ctypes.byref(ms)), "mwrt_last_kernel_ms")

@@ -489,5 +489,36 @@ def test_device_math_helpers(gpu_ctx):
     assert np.abs(lg[big] / rl[big] - 1).max() < 5e-16
     assert np.abs(lg[~big] - rl[~big]).max() < 1e-21 + 5e-16 * np.abs(rl[~big]).max()   # relative accuracy near 1
     assert lg[np.flatnonzero(y == 1.0)[0]] == 0.0
-    assert np.abs(dv * y / x - 1)[x != 0].max() < 1e-15
-    assert np.abs(dv1 * y / x - 1)[x != 0].max() < 1e-13
+    nz = x != 0
+    assert np.abs(dv[nz] * y[nz] / x[nz] - 1).max() < 1e-15
+    assert np.abs(dv1[nz] * y[nz] / x[nz] - 1).max() < 1e-13
+
+
+def test_context_is_safe_across_python_threads(gpu_ctx):
+    """Several Python threads hammering ONE context (ctypes releases the GIL): calls are serialised per
+    context, so every thread gets bitwise what the same call returns single-threaded."""
+    import threading
+    P = pr.synthetic_profiles(64, 80)
+
+    def call(k):
+        sl = slice(8 * k, 8 * k + 8)
+        return gpu_ctx.tb_batch("R24" if k % 2 else "R98", P["z"][sl], P["p"][sl], P["t"][sl], P["rh"][sl],
+                                pr.HATPRO_FRQS[: 14 - k], pr.BENCH_ELEVATIONS_7[: 7 - (k % 3)])[0]
+
+    expect = [call(k) for k in range(8)]
+    errs = []
+
+    def work(k):
+        try:
+            for _ in range(20):
+                if not np.array_equal(call(k), expect[k]):
+                    errs.append(k)
+        except Exception as exc:          # noqa: BLE001
+            errs.append(repr(exc))
+
+    threads = [threading.Thread(target=work, args=(k,)) for k in range(8)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errs, errs
