@@ -522,3 +522,26 @@ def test_context_is_safe_across_python_threads(gpu_ctx):
     for t in threads:
         t.join()
     assert not errs, errs
+
+
+def test_wrapper_cli_script(gpu_ctx, tmp_path):
+    """The script form of the wrapper (reference __main__, PyRTlib_processing.py:203-211): -i in -o out."""
+    import subprocess
+    import sys
+    from test_host_logic import make_ds
+    from mwr_fast_forward_operators_and_lbls_amd.dataset import Dataset
+    ds, P = make_ds(ntime=4, ncrop=2, nlev=180, elev=tuple(pr.REFERENCE_ELEVATIONS))
+    inp, out = str(tmp_path / "in.npz"), str(tmp_path / "out.nc")
+    ds.to_npz(inp)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-m", "mwr_fast_forward_operators_and_lbls_amd.pyrtlib_processing",
+                        "-i", inp, "--output", out], cwd=root, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    back = Dataset.from_netcdf3(out)
+    tb = back["TBs_PyRTlib_R24"].values
+    assert tb.shape == (4, 14, 10, 2) and np.isfinite(tb).all()
+    ref = lo.tb_cloud_rte(sp.get_model("R24"), P["z"][3], P["p"][3], P["t"][3], P["rh"][3], pr.HATPRO_FRQS,
+                          pr.REFERENCE_ELEVATIONS)["tbtotal"].reshape(10, 14)
+    assert np.abs(tb[1, :, :, 1].T - ref).max() <= TOL_K            # profile 3 = (time 1, Crop 1)
+    for tag in ("R17", "R98", "R20"):
+        assert "TBs_PyRTlib_" + tag in back
