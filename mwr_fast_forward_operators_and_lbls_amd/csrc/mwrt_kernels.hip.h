@@ -575,7 +575,7 @@ __global__ void __launch_bounds__(MAXT)
 k_tb_fused(const FusedArgs A) {
   static_assert(NFC % NFK == 0, "NFC must be a multiple of NFK");
   constexpr int NPASS = NFC / NFK;
-  extern __shared__ double lds[];
+  extern __shared__ __attribute__((aligned(16))) double lds[];     // 16-B base: wide ds_read stays aligned (guide G17)
   const int tid = threadIdx.x;
   const int lane = tid & (WAVE - 1);
   const int wave = tid / WAVE;
@@ -798,7 +798,7 @@ enum { SPO_DENS = 0, SPO_PE2, SPO_YMUL, SPO_COUNT };
 template <int NA>
 __global__ void __launch_bounds__(256)
 k_tb_spectral(const SpectralArgs A) {
-  extern __shared__ double lds[];
+  extern __shared__ __attribute__((aligned(16))) double lds[];     // 16-B base: wide ds_read stays aligned (guide G17)
   const int tid = threadIdx.x;
   const int nthreads = blockDim.x;
   const int64_t prof = blockIdx.x;
