@@ -293,8 +293,24 @@ int mwrt_model_create(mwrt_context* c, const mwrt_model_desc* desc, mwrt_model**
   mwrt_model* m = new (std::nothrow) mwrt_model();
   if (!m) return fail(MWRT_ERR_OUT_OF_MEMORY, "host allocation failed");
   static_cast<mwrt_model_desc&>(m->h_desc) = *desc;
-  for (int k = 0; k < MWRT_MAX_O2_LINES; ++k)
-    m->h_desc.o2_rf2[k] = (k < desc->n_o2 && desc->o2_f[k] != 0.0) ? 1.0 / (desc->o2_f[k] * desc->o2_f[k]) : 0.0;
+  std::memset(m->h_desc.o2r, 0, sizeof(m->h_desc.o2r));
+  std::memset(m->h_desc.h2or, 0, sizeof(m->h_desc.h2or));
+  for (int k = 0; k < MWRT_MAX_O2_LINES; ++k) {
+    const double rf2 = (k < desc->n_o2 && desc->o2_f[k] != 0.0) ? 1.0 / (desc->o2_f[k] * desc->o2_f[k]) : 0.0;
+    m->h_desc.o2_rf2[k] = rf2;
+    O2Rec& r = m->h_desc.o2r[k];
+    r.f = desc->o2_f[k]; r.s300rf2 = desc->o2_s300[k] * rf2; r.be = desc->o2_be[k]; r.w300 = desc->o2_w300[k];
+    r.y0 = desc->o2_y0[k]; r.y1 = desc->o2_y1[k]; r.g0 = desc->o2_g0[k]; r.g1 = desc->o2_g1[k];
+    r.dnu0 = desc->o2_dnu0[k]; r.dnu1 = desc->o2_dnu1[k];
+  }
+  for (int k = 0; k < MWRT_MAX_H2O_LINES; ++k) {
+    H2ORec& r = m->h_desc.h2or[k];
+    const double fl = desc->h2o_fl[k];
+    r.fl = fl; r.s1 = (k < desc->n_h2o && fl != 0.0) ? desc->h2o_s1[k] / (fl * fl) : 0.0; r.b2 = desc->h2o_b2[k];
+    r.w0 = desc->h2o_w0[k]; r.x = desc->h2o_x[k]; r.w0s = desc->h2o_w0s[k]; r.xs = desc->h2o_xs[k];
+    r.sh = desc->h2o_sh[k]; r.xh = desc->h2o_xh[k]; r.shs = desc->h2o_shs[k]; r.xhs = desc->h2o_xhs[k];
+    r.aair = desc->h2o_aair[k]; r.aself = desc->h2o_aself[k]; r.w2 = desc->h2o_w2[k];
+  }
   hipError_t e = hipMalloc((void**)&m->d_desc, sizeof(ModelFlat));
   if (e == hipSuccess) e = hipMemcpy(m->d_desc, &m->h_desc, sizeof(ModelFlat), hipMemcpyHostToDevice);
   if (e != hipSuccess) { if (m->d_desc) (void)hipFree(m->d_desc); delete m; return fail(MWRT_ERR_HIP, hipGetErrorString(e)); }

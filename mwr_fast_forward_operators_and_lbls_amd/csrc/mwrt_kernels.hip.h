@@ -26,8 +26,15 @@ constexpr double TAUMAX = 125.0;
 // through a CONSTANT-address-space pointer: the tables never change while a kernel runs, and
 // that is what lets the compiler fetch them with s_load (scalar cache, SGPR operands) instead of
 // 64 identical vector loads per wave.
+// Per-line records (array of structs): what the fused kernel's line loops read for line k sits in
+// one contiguous 128-byte record, so the compiler fetches it with one or two wide s_load and a
+// single wait per iteration instead of a dozen dwordx2 loads in three dependent groups.
+struct O2Rec { double f, s300rf2, be, w300, y0, y1, g0, g1, dnu0, dnu1, pad[6]; };      // 128 B
+struct H2ORec { double fl, s1, b2, w0, x, w0s, xs, sh, xh, shs, xhs, aair, aself, w2, pad[2]; };   // 128 B
 struct ModelFlat : mwrt_model_desc {
   double o2_rf2[MWRT_MAX_O2_LINES];      // 1 / F_k^2
+  O2Rec o2r[MWRT_MAX_O2_LINES];
+  H2ORec h2or[MWRT_MAX_H2O_LINES];
 };
 typedef const __attribute__((address_space(4))) ModelFlat* cmodel;
 typedef const __attribute__((address_space(4))) double* cdoubles;
@@ -269,13 +276,14 @@ struct H2OLine {          // per-(level, line) quantities, frequency independent
 __device__ __forceinline__ H2OLine h2o_line(cmodel M, int k, double pda, double pvap, double ti, double tiln,
                                             double ti2, bool shifted) {
   H2OLine q;
-  const double fl = M->h2o_fl[k];
-  q.w0 = M->h2o_w0[k] * pda * fexp(M->h2o_x[k] * tiln) + M->h2o_w0s[k] * pvap * fexp(M->h2o_xs[k] * tiln);
+  const auto& R = M->h2or[k];
+  const double fl = R.fl;
+  q.w0 = R.w0 * pda * fexp(R.x * tiln) + R.w0s * pvap * fexp(R.xs * tiln);
   double shift = 0.0;
   if (shifted) {
     // exponents / ln-T coefficients that are zero in the table cost nothing (uniform branches)
-    const double xh = M->h2o_xh[k], xhs = M->h2o_xhs[k], aa = M->h2o_aair[k], as = M->h2o_aself[k];
-    double sf = M->h2o_sh[k] * pda, ss = M->h2o_shs[k] * pvap;
+    const double xh = R.xh, xhs = R.xhs, aa = R.aair, as = R.aself;
+    double sf = R.sh * pda, ss = R.shs * pvap;
     if (aa != 0.0) sf *= (1.0 - aa * tiln);
     if (as != 0.0) ss *= (1.0 - as * tiln);
     if (xh != 0.0) sf *= fexp(xh * tiln);
@@ -283,7 +291,7 @@ __device__ __forceinline__ H2OLine h2o_line(cmodel M, int k, double pda, double 
     shift = sf + ss;
   }
   q.wsq = q.w0 * q.w0;
-  q.s = fdiv(M->h2o_s1[k] * ti2 * fexp(M->h2o_b2[k] * (1.0 - ti)), fl * fl);   // (f/fl)^2: f^2 applied at the end
+  q.s = R.s1 * ti2 * fexp(R.b2 * (1.0 - ti));                 // R.s1 = S1 / fl^2: the f^2 is applied at the end
   q.base = fdiv(q.w0, 562500.0 + q.wsq);
   q.c1 = fl + shift;
   q.sw = q.s * q.w0;
@@ -461,17 +469,18 @@ __device__ __forceinline__ void dry_absorb(cmodel M, const LevelState& L, const 
   double be_prev = -1.0, ebe = 1.0;
 
   for (int k = 0; k < nl; ++k) {
-    const double fk = M->o2_f[k];
-    const double y = ymul * (M->o2_y0[k] + M->o2_y1[k] * th1);
+    const auto& R = M->o2r[k];
+    const double fk = R.f;
+    const double y = ymul * (R.y0 + R.y1 * th1);
     double dnu = 0.0, gfac = 1.0;
     if (second) {
-      dnu = pe2 * (M->o2_dnu0[k] + M->o2_dnu1[k] * th1);
-      gfac = 1.0 + pe2 * (M->o2_g0[k] + M->o2_g1[k] * th1);
+      dnu = pe2 * (R.dnu0 + R.dnu1 * th1);
+      gfac = 1.0 + pe2 * (R.g0 + R.g1 * th1);
     }
-    const double df = M->o2_w300[k] * ((k == 0 && !second && M->o2_line1_dens) ? dens : den);
-    const double be = M->o2_be[k];
+    const double df = R.w300 * ((k == 0 && !second && M->o2_line1_dens) ? dens : den);
+    const double be = R.be;
     if (be != be_prev) { ebe = fexp(-be * th1); be_prev = be; }     // N- / N+ partners share BE (uniform branch)
-    const double str = M->o2_s300[k] * ebe * M->o2_rf2[k];           // * f^2 at the end
+    const double str = R.s300rf2 * ebe;                               // S300 / F^2 (the f^2 is applied at the end)
     const double c1 = fk + dnu;
     const double df2 = df * df;
     const double a = str * df * gfac;
