@@ -545,3 +545,39 @@ def test_wrapper_cli_script(gpu_ctx, tmp_path):
     assert np.abs(tb[1, :, :, 1].T - ref).max() <= TOL_K            # profile 3 = (time 1, Crop 1)
     for tag in ("R17", "R98", "R20"):
         assert "TBs_PyRTlib_" + tag in back
+
+
+def test_hip_graph_capture_of_the_four_model_sequence(gpu_ctx):
+    """The device entry point is capture-safe once frequencies/angles are cached: the wrapper's four
+    model runs (PyRTlib_processing.py:121-151) captured into ONE hipGraph and replayed."""
+    import torch
+    dev = torch.device("cuda:0")
+    P = pr.synthetic_profiles(200, 81)
+    frq, ang = pr.HATPRO_FRQS, pr.REFERENCE_ELEVATIONS
+    d = {k: torch.from_numpy(P[k]).to(dev) for k in ("z", "p", "t", "rh")}
+    models = ["R20", "R24", "R17", "R98"]
+    out = torch.zeros((4, 200, 10, 14), dtype=torch.float64, device=dev)
+    val = torch.zeros((4, 200), dtype=torch.uint8, device=dev)
+
+    def run(stream):
+        for i, m in enumerate(models):
+            gpu_ctx.tb_batch_device(m, 200, 180, d["z"].data_ptr(), d["p"].data_ptr(), d["t"].data_ptr(),
+                                    d["rh"].data_ptr(), frq, ang, out[i].data_ptr(), val[i].data_ptr(), stream=stream)
+
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        run(side.cuda_stream)                       # warm-up: uploads tables, frequencies, angles
+    side.synchronize()
+    eager = out.clone()
+    out.zero_()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g, stream=side):
+        run(torch.cuda.current_stream().cuda_stream)
+    assert float(out.abs().sum()) == 0.0            # capture records, it does not execute
+    g.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(out, eager) and bool((val == 1).all())
+    d["t"][7, 3] = float("nan")                     # graphs replay on the CURRENT buffer contents
+    g.replay()
+    torch.cuda.synchronize()
+    assert bool(torch.isnan(out[:, 7]).all()) and int(val[0, 7]) == 0 and torch.equal(out[:, 8:], eager[:, 8:])
