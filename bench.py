@@ -66,12 +66,26 @@ def cpu_baseline(tables, P, frq, ang, budget_s=20.0):
     for i in range(npy):
         lbl_oracle.tb_cloud_rte(tables, P["z"][i], P["p"][i], P["t"][i], P["rh"][i], frq, ang)
     dtp = time.perf_counter() - t0
+    # opportunistic: a genuine pyrtlib, ONLY if it is already importable on this box (never shipped or
+    # fetched; absent in the build image) -- BASELINE config 1: one profile, zenith, 14 channels
+    genuine = None
+    try:
+        from pyrtlib.tb_spectrum import TbCloudRTE as RefRTE      # noqa: F401
+        t0 = time.perf_counter()
+        rte = RefRTE(P["z"][0].copy(), P["p"][0], P["t"][0], P["rh"][0], frq, np.array([90.0]))
+        rte.init_absmdl(tables.name)
+        rte.satellite = False
+        ref_tb = rte.execute()["tbtotal"].values
+        genuine = {"value": len(frq) / (time.perf_counter() - t0), "cores": 1, "tbtotal": [float(v) for v in ref_tb]}
+    except Exception:                                              # ImportError here; anything else: not our problem
+        genuine = None
     return {"value": passes * n * ev / dt1, "unit": "TB evaluations/s", "cores": 1, "kind": "port",
             "sample": f"{passes} pass(es) over {n} of the {P['z'].shape[0]} profiles x {len(frq)} ch x {len(ang)} elev, "
                       f"oracle/lbl_oracle.c (pyrtlib loop order), {dt1:.1f} s on 1 core",
             "all_cores": {"value": P["z"].shape[0] * ev / dtn, "cores": cores, "seconds": round(dtn, 2)},
             "pyrtlib_shaped_numpy": {"value": npy * ev / dtp, "cores": 1, "profiles": npy,
-                                     "what": "oracle/lbl_oracle.py, pyrtlib's loop structure in NumPy"}}, tb, n
+                                     "what": "oracle/lbl_oracle.py, pyrtlib's loop structure in NumPy"},
+            "genuine_pyrtlib": genuine}, tb, n
 
 
 class _stdout_to_stderr:
@@ -209,6 +223,9 @@ def main():
             res["cpu_baseline"] = cb
             res["parity_check"] = {"max_abs_dev_K": float(np.abs(tb_gpu[:n] - tb_cpu).max()), "profiles": n,
                                    "against": "oracle/lbl_oracle.c (parity vs pyrtlib unpinned)"}
+            if cb.get("genuine_pyrtlib"):
+                ref_tb = np.array(cb["genuine_pyrtlib"].pop("tbtotal"))
+                res["parity_check"]["vs_genuine_pyrtlib_K"] = float(np.abs(tb_gpu[0, 0] - ref_tb).max())
         print(json.dumps(res), flush=True)
     if use_dist:
         dist.destroy_process_group()
