@@ -579,8 +579,11 @@ __device__ __forceinline__ void blank_outputs(const FusedArgs& A, int64_t prof, 
 // NFK = frequencies per K2 pass (rows of tau / B kept in LDS at a time): NFC = NPASS * NFK.
 // Keeping only NFK rows resident holds the workgroup under 40 KB of LDS, so FOUR 192-thread
 // workgroups (12 waves = 3 per SIMD) fit a CU and a 1000-profile batch is one resident round.
+#ifndef MWRT_MIN_WAVES
+#define MWRT_MIN_WAVES 1
+#endif
 template <int NFC, int NFK, int MAXT>
-__global__ void __launch_bounds__(MAXT)
+__global__ void __launch_bounds__(MAXT, (MAXT <= 256 ? MWRT_MIN_WAVES : 1))
 k_tb_fused(const FusedArgs A) {
   static_assert(NFC % NFK == 0, "NFC must be a multiple of NFK");
   constexpr int NPASS = NFC / NFK;
