@@ -204,7 +204,7 @@ def main():
             "config": {"workload": f"BASELINE configs[{args.config - 1}]: {nprof} synthetic profiles/GPU x {nf} HATPRO "
                                    f"channels x {nang} elevation(s), {nlev} levels, model {args.model}, clear-sky LBL "
                                    "absorption + slant-path RTE",
-                       "nprof_per_gpu": nprof, "nlev": nlev, "nf": nf, "nang": nang, "model": args.model,
+                       "nprof_per_gpu": nprof, "nlev": nlev, "nf": nf, "nang": nang, "absorption_model": args.model,
                        "sharding": f"profiles x{world}, final all_gather of {min(K, slots)} result batches"},
             "roofline": {"bound": "hbm", "achieved": gbs, "peak": roofline.HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": gbs / roofline.HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
