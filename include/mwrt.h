@@ -127,6 +127,21 @@ int mwrt_tb_batch_device(mwrt_context* ctx, const mwrt_model* model,
                          double* d_tb_out, uint8_t* d_valid_out, const mwrt_tb_extras* d_extras,
                          void* stream);
 
+/* Several absorption models over the SAME profiles in one launch (and one host->device copy): what
+ * the wrapper does four times per profile, R20/R24/R17/R98 (PyRTlib_processing.py:121-151).
+ * nmodels <= 8; tb_out [nmodels][nprof][nang][nf], valid_out [nmodels][nprof]. */
+int mwrt_tb_batch_multi(mwrt_context* ctx, int32_t nmodels, const mwrt_model* const* models,
+                        int64_t nprof, int32_t nlev,
+                        const double* z_km, const double* p_hpa, const double* t_k, const double* rh_frac,
+                        int32_t nf, const double* frq_ghz, int32_t nang, const double* elev_deg,
+                        double* tb_out, uint8_t* valid_out);
+int mwrt_tb_batch_multi_device(mwrt_context* ctx, int32_t nmodels, const mwrt_model* const* models,
+                               int64_t nprof, int32_t nlev,
+                               const double* d_z_km, const double* d_p_hpa, const double* d_t_k,
+                               const double* d_rh_frac,
+                               int32_t nf, const double* frq_ghz, int32_t nang, const double* elev_deg,
+                               double* d_tb_out, uint8_t* d_valid_out, void* stream);
+
 /* RTEquation.clearsky_absorption for a batch: awet, adry [nprof][nf][nlev] in Np/km
  * (exposes kernel K1 alone, for parity tests and the roofline measurement). HOST buffers. */
 int mwrt_absorption_batch(mwrt_context* ctx, const mwrt_model* model,

@@ -50,6 +50,10 @@ SIGNATURES = {
                                      _vp, _vp, ctypes.POINTER(MwrtTbExtras)]),
     "mwrt_tb_batch_device": (ctypes.c_int, [_vp, _vp, _i64, _i32, _vp, _vp, _vp, _vp, _i32, _vp, _i32, _vp,
                                             _vp, _vp, ctypes.POINTER(MwrtTbExtras), _vp]),
+    "mwrt_tb_batch_multi": (ctypes.c_int, [_vp, _i32, ctypes.POINTER(_vp), _i64, _i32, _vp, _vp, _vp, _vp, _i32, _vp,
+                                           _i32, _vp, _vp, _vp]),
+    "mwrt_tb_batch_multi_device": (ctypes.c_int, [_vp, _i32, ctypes.POINTER(_vp), _i64, _i32, _vp, _vp, _vp, _vp, _i32,
+                                                  _vp, _i32, _vp, _vp, _vp, _vp]),
     "mwrt_absorption_batch": (ctypes.c_int, [_vp, _vp, _i64, _i32, _vp, _vp, _vp, _i32, _vp, _vp, _vp]),
     "mwrt_absorption_batch_device": (ctypes.c_int, [_vp, _vp, _i64, _i32, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp]),
     "mwrt_set_kernel_policy": (ctypes.c_int, [_vp, ctypes.c_int]),
@@ -221,6 +225,32 @@ class Context:
             nf, _ptr(frq), nang, _ptr(elev), _ptr(tb), _ptr(valid),
             ctypes.byref(exs) if exs is not None else None), "mwrt_tb_batch")
         return (tb, valid, ex) if extras else (tb, valid)
+
+    @_serialised
+    def tb_batch_multi(self, models, z, p, t, rh, frq, elev):
+        """Several models over the same profiles in ONE launch: tb [nmodels][nprof][nang][nf], valid [nmodels][nprof]."""
+        z = _f64(z)
+        if z.ndim != 2:
+            raise ValueError("profiles must be [nprof][nlev]")
+        nprof, nlev = z.shape
+        p, t, rh = _f64(p, z.shape, "p"), _f64(t, z.shape, "t"), _f64(rh, z.shape, "rh")
+        frq, elev = _f64(frq).ravel(), _f64(elev).ravel()
+        handles = (ctypes.c_void_p * len(models))(*[self.model(m) for m in models])
+        tb = np.empty((len(models), nprof, elev.size, frq.size))
+        valid = np.empty((len(models), nprof), dtype=np.uint8)
+        self._check(self._lib.mwrt_tb_batch_multi(
+            self._handle, len(models), handles, nprof, nlev, _ptr(z), _ptr(p), _ptr(t), _ptr(rh),
+            frq.size, _ptr(frq), elev.size, _ptr(elev), _ptr(tb), _ptr(valid)), "mwrt_tb_batch_multi")
+        return tb, valid
+
+    @_serialised
+    def tb_batch_multi_device(self, models, nprof, nlev, d_z, d_p, d_t, d_rh, frq, elev, d_tb, d_valid, stream: int = 0):
+        frq, elev = _f64(frq).ravel(), _f64(elev).ravel()
+        handles = (ctypes.c_void_p * len(models))(*[self.model(m) for m in models])
+        self._check(self._lib.mwrt_tb_batch_multi_device(
+            self._handle, len(models), handles, int(nprof), int(nlev), _ptr(d_z), _ptr(d_p), _ptr(d_t), _ptr(d_rh),
+            frq.size, _ptr(frq), elev.size, _ptr(elev), _ptr(d_tb), _ptr(d_valid),
+            ctypes.c_void_p(stream) if stream else None), "mwrt_tb_batch_multi_device")
 
     @_serialised
     def absorption_batch(self, model, p, t, rh, frq):

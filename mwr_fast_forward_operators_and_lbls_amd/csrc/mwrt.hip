@@ -143,7 +143,7 @@ int launch_fused(mwrt_context* c, FusedArgs a, int64_t nprof, hipStream_t st) {
   size_t lds = 0;
   if (!plan_fused(c, NFC, a.nlev, a.nf, a.nang, &a.g, &lds))
     return fail(MWRT_ERR_UNSUPPORTED, "LDS budget exceeded (nlev x nang too large)");
-  dim3 grid((unsigned)nprof, (unsigned)nchunks), block(threads);
+  dim3 grid((unsigned)nprof /* = nmodels x profiles */, (unsigned)nchunks), block(threads);
   // valid[] = 1 is written by the kernel itself when one workgroup owns the profile; with several
   // frequency chunks per profile the flags are preset here and the kernel only lowers/raises them
   a.write_valid = nchunks == 1;
@@ -326,29 +326,35 @@ int mwrt_model_destroy(mwrt_context* c, mwrt_model* m) {
   return MWRT_OK;
 }
 
-int mwrt_tb_batch_device(mwrt_context* c, const mwrt_model* m, int64_t nprof, int32_t nlev,
-                         const double* d_z, const double* d_p, const double* d_t, const double* d_rh,
-                         int32_t nf, const double* frq, int32_t nang, const double* elev,
-                         double* d_tb, uint8_t* d_valid, const mwrt_tb_extras* ex, void* stream) {
-  int rc = check_common(c, m, nprof, nlev, nf);
-  if (rc) return rc;
+// core of every TB entry point: nmodels absorption models x nprof profiles in ONE launch
+static int tb_launch(mwrt_context* c, int nmodels, const mwrt_model* const* ms, int64_t nprof, int32_t nlev,
+                     const double* d_z, const double* d_p, const double* d_t, const double* d_rh,
+                     int32_t nf, const double* frq, int32_t nang, const double* elev,
+                     double* d_tb, uint8_t* d_valid, const mwrt_tb_extras* ex, void* stream) {
+  if (nmodels < 1 || nmodels > MAX_MULTI || !ms) return fail(MWRT_ERR_INVALID_ARGUMENT, "nmodels must be 1..8");
+  for (int i = 0; i < nmodels; ++i) {
+    int rc = check_common(c, ms[i], nprof, nlev, nf);
+    if (rc) return rc;
+  }
   if (nang < 1 || nang > MWRT_MAX_ANGLES) return fail(MWRT_ERR_INVALID_ARGUMENT, "nang out of range");
   if (!d_z || !d_p || !d_t || !d_rh || !frq || !elev || !d_tb || !d_valid)
     return fail(MWRT_ERR_INVALID_ARGUMENT, "null buffer");
+  const int64_t rows = nprof * nmodels;
+  if (rows > 2147483647LL) return fail(MWRT_ERR_UNSUPPORTED, "nmodels x nprof exceeds grid limit");
   HIP_TRY(hipSetDevice(c->device));
   hipStream_t st = stream ? (hipStream_t)stream : c->stream;
   if (nprof == 0) return MWRT_OK;
-  const size_t nout = (size_t)nprof * nang * nf;
+  const size_t nout = (size_t)rows * nang * nf;
   if (any_nan(frq, nf) || any_nan(elev, nang)) {
     // check_for_nans covers frqs and ang too (PyRTlib_processing.py:77-78): everything stays NaN
     HIP_TRY(hipMemsetAsync(d_tb, 0xFF, nout * sizeof(double), st));
-    HIP_TRY(hipMemsetAsync(d_valid, 0, (size_t)nprof, st));
+    HIP_TRY(hipMemsetAsync(d_valid, 0, (size_t)rows, st));
     if (ex) {
       if (ex->tbatm) HIP_TRY(hipMemsetAsync(ex->tbatm, 0xFF, nout * sizeof(double), st));
       if (ex->tmr) HIP_TRY(hipMemsetAsync(ex->tmr, 0xFF, nout * sizeof(double), st));
       if (ex->tauwet) HIP_TRY(hipMemsetAsync(ex->tauwet, 0xFF, nout * sizeof(double), st));
       if (ex->taudry) HIP_TRY(hipMemsetAsync(ex->taudry, 0xFF, nout * sizeof(double), st));
-      if (ex->taulay) HIP_TRY(hipMemsetAsync(ex->taulay, 0xFF, (size_t)nprof * nf * nlev * sizeof(double), st));
+      if (ex->taulay) HIP_TRY(hipMemsetAsync(ex->taulay, 0xFF, (size_t)rows * nf * nlev * sizeof(double), st));
     }
     return MWRT_OK;
   }
@@ -359,32 +365,82 @@ int mwrt_tb_batch_device(mwrt_context* c, const mwrt_model* m, int64_t nprof, in
       return fail(MWRT_ERR_INVALID_ARGUMENT, "elevation angles must lie in (0, 180) degrees");
     am[a] = 1.0 / std::sin(elev[a] * M_PI / 180.0);
   }
-  rc = upload_small(c, c->d_frq, c->h_frq, frq, nf, st); if (rc) return rc;
+  int rc = upload_small(c, c->d_frq, c->h_frq, frq, nf, st); if (rc) return rc;
   rc = upload_small(c, c->d_am, c->h_am, am.data(), nang, st); if (rc) return rc;
 
-  // automatic = fused: measured on MI355X the spectral kernel only ties it on the 1000-frequency grid
-  // (profiles/r01_finegrid.txt), so it stays opt-in until it wins
+  // automatic = fused: measured on MI355X the spectral kernel loses to it even on the 1000-frequency
+  // grid (profiles/r01_finegrid.txt), so it stays opt-in until it wins
   const bool spectral = c->kernel_policy == 2;
   if (spectral) {
+    if (nmodels != 1) return fail(MWRT_ERR_UNSUPPORTED, "the spectral kernel evaluates one model per launch");
     SpectralArgs sa{};
-    sa.M = m->d_desc; sa.z = d_z; sa.p = d_p; sa.t = d_t; sa.rh = d_rh;
+    sa.M = ms[0]->d_desc; sa.z = d_z; sa.p = d_p; sa.t = d_t; sa.rh = d_rh;
     sa.frq = c->d_frq.as<double>(); sa.airmass = c->d_am.as<double>();
     sa.tb = d_tb; sa.valid = d_valid;
     if (ex) { sa.tbatm = ex->tbatm; sa.tmr = ex->tmr; sa.tauwet = ex->tauwet; sa.taudry = ex->taudry; sa.taulay = ex->taulay; }
     sa.nlev = nlev; sa.nf = nf; sa.nang = nang;
-    return launch_spectral(c, m, sa, nprof, st);
+    return launch_spectral(c, ms[0], sa, nprof, st);
   }
   FusedArgs a{};
-  a.M = m->d_desc; a.z = d_z; a.p = d_p; a.t = d_t; a.rh = d_rh;
+  for (int i = 0; i < nmodels; ++i) a.Ms[i] = ms[i]->d_desc;
+  a.nprof_in = nprof;
+  a.z = d_z; a.p = d_p; a.t = d_t; a.rh = d_rh;
   a.frq = c->d_frq.as<double>(); a.airmass = c->d_am.as<double>();
   a.tb = d_tb; a.valid = d_valid;
   if (ex) { a.tbatm = ex->tbatm; a.tmr = ex->tmr; a.tauwet = ex->tauwet; a.taudry = ex->taudry; a.taulay = ex->taulay; }
   a.nlev = nlev; a.nf = nf; a.nang = nang;
   switch (pick_nfc_fused(c, nlev, nf, nang)) {
-    case 8: return launch_fused<8>(c, a, nprof, st);
-    case 14: return launch_fused<14>(c, a, nprof, st);
-    default: return launch_fused<16>(c, a, nprof, st);
+    case 8: return launch_fused<8>(c, a, rows, st);
+    case 14: return launch_fused<14>(c, a, rows, st);
+    default: return launch_fused<16>(c, a, rows, st);
   }
+}
+
+int mwrt_tb_batch_device(mwrt_context* c, const mwrt_model* m, int64_t nprof, int32_t nlev,
+                         const double* d_z, const double* d_p, const double* d_t, const double* d_rh,
+                         int32_t nf, const double* frq, int32_t nang, const double* elev,
+                         double* d_tb, uint8_t* d_valid, const mwrt_tb_extras* ex, void* stream) {
+  if (!c || !m) return fail(MWRT_ERR_INVALID_ARGUMENT, "null context or model");
+  return tb_launch(c, 1, &m, nprof, nlev, d_z, d_p, d_t, d_rh, nf, frq, nang, elev, d_tb, d_valid, ex, stream);
+}
+
+int mwrt_tb_batch_multi_device(mwrt_context* c, int32_t nmodels, const mwrt_model* const* models, int64_t nprof,
+                               int32_t nlev, const double* d_z, const double* d_p, const double* d_t,
+                               const double* d_rh, int32_t nf, const double* frq, int32_t nang, const double* elev,
+                               double* d_tb, uint8_t* d_valid, void* stream) {
+  if (!c) return fail(MWRT_ERR_INVALID_ARGUMENT, "null context");
+  return tb_launch(c, nmodels, models, nprof, nlev, d_z, d_p, d_t, d_rh, nf, frq, nang, elev, d_tb, d_valid, nullptr,
+                   stream);
+}
+
+int mwrt_tb_batch_multi(mwrt_context* c, int32_t nmodels, const mwrt_model* const* models, int64_t nprof, int32_t nlev,
+                        const double* z, const double* p, const double* t, const double* rh,
+                        int32_t nf, const double* frq, int32_t nang, const double* elev,
+                        double* tb, uint8_t* valid) {
+  if (!c || !models || nmodels < 1 || nmodels > MAX_MULTI) return fail(MWRT_ERR_INVALID_ARGUMENT, "bad context / models");
+  if (!z || !p || !t || !rh || !frq || !elev || !tb || !valid) return fail(MWRT_ERR_INVALID_ARGUMENT, "null buffer");
+  if (nprof < 0 || nlev < 2 || nf < 1 || nang < 1) return fail(MWRT_ERR_INVALID_ARGUMENT, "bad sizes");
+  if (nprof == 0) return MWRT_OK;
+  HIP_TRY(hipSetDevice(c->device));
+  hipStream_t st = c->stream;
+  const size_t nin = (size_t)nprof * nlev, rows = (size_t)nprof * nmodels, nout = rows * nang * nf;
+  HIP_TRY(c->d_in.reserve(4 * nin * sizeof(double)));
+  HIP_TRY(c->d_out.reserve(nout * sizeof(double)));
+  HIP_TRY(c->d_valid.reserve(rows));
+  double* din = c->d_in.as<double>();
+  const double* src[4] = {z, p, t, rh};
+  for (int k = 0; k < 4; ++k)                        // the profiles cross PCIe once for all models
+    HIP_TRY(hipMemcpyAsync(din + k * nin, src[k], nin * sizeof(double), hipMemcpyHostToDevice, st));
+  int rc = tb_launch(c, nmodels, models, nprof, nlev, din, din + nin, din + 2 * nin, din + 3 * nin, nf, frq, nang, elev,
+                     c->d_out.as<double>(), c->d_valid.as<uint8_t>(), nullptr, st);
+  if (rc) return rc;
+  HIP_TRY(hipMemcpyAsync(tb, c->d_out.p, nout * sizeof(double), hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipMemcpyAsync(valid, c->d_valid.p, rows, hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipStreamSynchronize(st));
+  const double qnan = std::nan("");
+  for (size_t i = 0; i < rows; ++i)
+    if (valid[i] == 2) for (size_t o = 0; o < (size_t)nang * nf; ++o) tb[i * nang * nf + o] = qnan;
+  return MWRT_OK;
 }
 
 int mwrt_tb_batch(mwrt_context* c, const mwrt_model* m, int64_t nprof, int32_t nlev,

@@ -544,8 +544,12 @@ __device__ __forceinline__ double layer_value(double x1, double x0, bool& neg) {
 // ---------------------------------------------------------------------------------------------
 // fused kernel: profile in -> TB out
 // ---------------------------------------------------------------------------------------------
+constexpr int MAX_MULTI = 8;   // absorption models evaluated by one launch (the wrapper runs four)
+
 struct FusedArgs {
-  const ModelFlat* M;
+  // blockIdx.x enumerates (model, profile): outputs are [nmodels][nprof]..., inputs [nprof]...
+  const ModelFlat* Ms[MAX_MULTI];
+  int64_t nprof_in;        // profiles per model
   const double* z; const double* p; const double* t; const double* rh;   // [nprof][nlev]
   const double* frq;       // [nf] device
   const double* airmass;   // [nang] device: 1/sin(elev)
@@ -593,11 +597,13 @@ k_tb_fused(const FusedArgs A) {
   const int wave = tid / WAVE;
   const int nthreads = blockDim.x;
   const int nwaves = nthreads / WAVE;
-  const int64_t prof = blockIdx.x;
+  const int64_t prof = blockIdx.x;                       // output row: model * nprof_in + profile
+  const int mi = (int)(prof / A.nprof_in);
+  const int64_t pin = prof - mi * A.nprof_in;            // input profile
   const int jbase = blockIdx.y * NFC;
   const int nfc = min(NFC, A.nf - jbase);
   const int nlev = A.nlev, nang = A.nang, ld = A.g.ldrow;
-  const cmodel M = (cmodel)A.M;
+  const cmodel M = (cmodel)A.Ms[mi];
   const cdoubles cfrq = (cdoubles)A.frq;
   const cdoubles cam = (cdoubles)A.airmass;
 
@@ -626,7 +632,7 @@ k_tb_fused(const FusedArgs A) {
   __syncthreads();
 
   const bool active = tid < nlev;
-  const int64_t off = prof * nlev + (active ? tid : 0);
+  const int64_t off = pin * nlev + (active ? tid : 0);
   const double zi = A.z[off], pi = A.p[off], ti = A.t[off], rhi = A.rh[off];
   if (active && (isnan(zi) || isnan(pi) || isnan(ti) || isnan(rhi))) atomicOr(&s_flag, 1);
   __syncthreads();
@@ -655,7 +661,7 @@ k_tb_fused(const FusedArgs A) {
   double tw[NFC], td[NFC];
   bool neg = false;
   {
-    const double z0 = A.z[prof * nlev];       // execute() works in height above the antenna
+    const double z0 = A.z[pin * nlev];        // execute() works in height above the antenna
     const double dz = (active && tid > 0) ? ((zi - z0) - (A.z[off - 1] - z0)) : 0.0;
     const bool seam = (lane == 0) && (wave > 0);
     const bool has_prev = active && tid > 0;

@@ -4,9 +4,10 @@
 Mirror of reference python_src/proc/PyRTlib_processing.py:83-197 (same function names,
 argument meaning, output variable names / dims / attrs, NaN behaviour and CLI flags), with the
 triple Python loop over (time, Crop, elevation) x 4 models (:99-151, 41 600 ``execute()`` calls
-on the real data set) replaced by ONE batched HIP call per model: all (time, Crop) profiles are
-packed once into contiguous ``[nprof][nlev]`` ground->top arrays and all elevations ride in the
-same launch (absorption is angle-independent, so it is evaluated once instead of 10 times).
+on the real data set) replaced by ONE batched HIP launch: all (time, Crop) profiles are packed
+once into contiguous ``[nprof][nlev]`` ground->top arrays, all elevations and all four models
+ride in the same launch (absorption is angle-independent, so it is evaluated once per model
+instead of 10 times; the profiles cross PCIe once instead of four times).
 
 Input contract (producer: preprocessing4all.py:807-814, :1195-1203): ``Level_z`` [m],
 ``Level_Pressure`` [hPa], ``Level_Temperature`` [K], ``Level_RH`` [%], dims
@@ -88,8 +89,8 @@ def _attrs(tag):
 
 
 def derive_TBs4PyRTlib(ds, args=None):
-    """Reference :83-197.  Every model run goes to the HIP library (one batched call per model);
-    there is no other engine."""
+    """Reference :83-197.  All four model runs go to the HIP library in one batched call; there is no
+    other engine."""
     frqs = np.array([22.24, 23.04, 23.84, 25.44, 26.24, 27.84, 31.4, 51.26, 52.28,
                      53.86, 54.94, 56.66, 57.3, 58.])
     nf = len(frqs)
@@ -98,10 +99,12 @@ def derive_TBs4PyRTlib(ds, args=None):
     z, p, t, rh, ntime, ncrop = pack_profiles(ds)
     nprof = ntime * ncrop
 
+    # all four models over the same profiles in ONE launch (and one host->device copy of the profiles)
+    tables = [spectroscopy.get_model(mdl) for _, mdl in MODEL_RUNS]
+    tb_all, valid_all = _native.default_context().tb_batch_multi(tables, z, p, t, rh, frqs, ang)
     results = {}
-    for suffix, mdl in MODEL_RUNS:
-        tables = spectroscopy.get_model(mdl)
-        tb, valid = _native.default_context().tb_batch(tables, z, p, t, rh, frqs, ang)
+    for k, (suffix, mdl) in enumerate(MODEL_RUNS):
+        tb, valid = tb_all[k], valid_all[k]
         bad = np.nonzero(valid == 2)[0]
         if bad.size:     # the reference does not catch pyrtlib's exception (:123-127)
             raise ValueError("Error encountered in exponential_integration "

@@ -44,6 +44,11 @@ class OracleContext:
                                       np.asarray(frq, dtype=float).ravel(), np.asarray(elev, dtype=float).ravel())
         return (tb, valid, ex) if extras else (tb, valid)
 
+    def tb_batch_multi(self, models, z, p, t, rh, frq, elev):
+        import numpy as np
+        res = [self.tb_batch(m, z, p, t, rh, frq, elev) for m in models]
+        return np.stack([r[0] for r in res]), np.stack([r[1] for r in res])
+
 
 @pytest.fixture
 def oracle_ctx(monkeypatch):

@@ -581,3 +581,24 @@ def test_hip_graph_capture_of_the_four_model_sequence(gpu_ctx):
     g.replay()
     torch.cuda.synchronize()
     assert bool(torch.isnan(out[:, 7]).all()) and int(val[0, 7]) == 0 and torch.equal(out[:, 8:], eager[:, 8:])
+
+
+def test_multi_model_launch(gpu_ctx):
+    """Four models in one launch == four single-model launches, bitwise; NaN rows blank in every model."""
+    P = pr.synthetic_profiles(300, 82)
+    P["rh"][17, 100] = np.nan
+    models = ["R20", "R24", "R17", "R98"]
+    ang = pr.REFERENCE_ELEVATIONS
+    tbm, vm = gpu_ctx.tb_batch_multi(models, P["z"], P["p"], P["t"], P["rh"], pr.HATPRO_FRQS, ang)
+    assert tbm.shape == (4, 300, 10, 14) and vm.shape == (4, 300)
+    for k, m in enumerate(models):
+        tb, v = gpu_ctx.tb_batch(m, P["z"], P["p"], P["t"], P["rh"], pr.HATPRO_FRQS, ang)
+        assert np.array_equal(v, vm[k]) and v[17] == 0
+        assert np.array_equal(np.nan_to_num(tb), np.nan_to_num(tbm[k])) and np.isnan(tbm[k, 17]).all()
+    import dataclasses
+    bad = dataclasses.replace(sp.get_model("R98"), name="R98_negcont_multi", h2o_cf=-1e-6)
+    tbm, vm = gpu_ctx.tb_batch_multi(["R24", bad], P["z"][:5], P["p"][:5], P["t"][:5], P["rh"][:5], pr.HATPRO_FRQS, ang[:2])
+    assert (vm[0] == 1).all() and (vm[1] == 2).all() and np.isnan(tbm[1]).all() and np.isfinite(tbm[0]).all()
+    from mwr_fast_forward_operators_and_lbls_amd._native import MwrtError
+    with pytest.raises(MwrtError):
+        gpu_ctx.tb_batch_multi(["R24"] * 9, P["z"][:2], P["p"][:2], P["t"][:2], P["rh"][:2], pr.HATPRO_FRQS, ang[:1])
