@@ -602,3 +602,37 @@ def test_multi_model_launch(gpu_ctx):
     from mwr_fast_forward_operators_and_lbls_amd._native import MwrtError
     with pytest.raises(MwrtError):
         gpu_ctx.tb_batch_multi(["R24"] * 9, P["z"][:2], P["p"][:2], P["t"][:2], P["rh"][:2], pr.HATPRO_FRQS, ang[:1])
+
+
+@pytest.mark.parametrize("policy", [1, 2])
+def test_layer_integration_special_branches(gpu_ctx, policy):
+    """exponential_integration's special cases on the GPU path (rule 26: a rare branch needs an input
+    that forces it): adjacent levels with IDENTICAL state (|x_i - x_{i-1}| < 1e-9 -> x_i), levels with
+    rh = 0 next to moist ones (a zero -> arithmetic mean), and runs of zeros (0/0 guarded)."""
+    nlev = 64
+    z = np.linspace(0.05, 20.0, nlev)
+    p = 1010.0 * np.exp(-z / 7.6)
+    t = 289.0 - 6.2 * np.minimum(z, 11.0)
+    rh = 0.6 * np.exp(-z / 3.0)
+    for i in range(4, nlev, 6):                 # pairs of levels sharing p, T, rh (only z differs)
+        p[i], t[i], rh[i] = p[i - 1], t[i - 1], rh[i - 1]
+    rh[10:14] = 0.0                             # dry block: moist->0, 0->0, 0->moist transitions
+    rh[30] = 0.0
+    rh[50:] = 0.0
+    Z, Pp, T, RH = (np.tile(a, (3, 1)) for a in (z, p, t, rh))
+    ang = np.array([90.0, 7.0])
+    gpu_ctx.set_kernel_policy(policy)
+    try:
+        tb, valid, ex = gpu_ctx.tb_batch("R24", Z, Pp, T, RH, pr.HATPRO_FRQS, ang, extras=True)
+    finally:
+        gpu_ctx.set_kernel_policy(0)
+    assert (valid == 1).all()
+    m = sp.get_model("R24")
+    r = lo.tb_cloud_rte(m, z, p, t, rh, pr.HATPRO_FRQS, ang)
+    assert np.abs(tb[1].ravel() - r["tbtotal"]).max() <= TOL_K
+    assert np.allclose(ex["tauwet"][1].ravel(), r["tauwet"], rtol=1e-9)
+    lay = r["taulay"][:, 0, :]                 # zenith layers (first angle is 90 deg)
+    assert np.allclose(ex["taulay"][1], lay, rtol=1e-9, atol=1e-18)
+    aw, _ = lo.absorption_profile(m, p, t, rh, pr.HATPRO_FRQS[:1])
+    assert aw[0, 11] == 0.0 and aw[0, 12] == 0.0 and aw[0, 9] > 0.0     # the branches really were exercised
+    assert abs(aw[0, 4] - aw[0, 3]) < 1e-9
