@@ -636,3 +636,34 @@ def test_layer_integration_special_branches(gpu_ctx, policy):
     aw, _ = lo.absorption_profile(m, p, t, rh, pr.HATPRO_FRQS[:1])
     assert aw[0, 11] == 0.0 and aw[0, 12] == 0.0 and aw[0, 9] > 0.0     # the branches really were exercised
     assert abs(aw[0, 4] - aw[0, 3]) < 1e-9
+
+
+def test_extreme_inputs_track_the_oracle(gpu_ctx):
+    """Inputs far outside radiosonde climatology (150-340 K, 0.05-1100 hPa, rh 0-1.5, repeated heights,
+    coarse and very fine layers): no validation happens on either side (pyrtlib does none), so the
+    HIP path must simply reproduce the oracle's numbers, finite or not."""
+    from oracle import c_oracle
+    rng = np.random.default_rng(2024)
+    nprof, nlev = 24, 96
+    dz = rng.choice([0.0, 1e-6, 0.01, 0.2, 2.0], size=(nprof, nlev), p=[0.05, 0.05, 0.3, 0.4, 0.2])
+    z = np.cumsum(dz, axis=1) + rng.uniform(0, 4, (nprof, 1))
+    p = np.sort(rng.uniform(0.05, 1100.0, (nprof, nlev)), axis=1)[:, ::-1].copy()
+    t = rng.uniform(150.0, 340.0, (nprof, nlev))
+    rh = rng.uniform(0.0, 1.5, (nprof, nlev)) * (rng.random((nprof, nlev)) > 0.1)
+    frq = np.array([1.0, 22.235, 31.4, 57.3, 60.3061, 118.7503, 183.31, 325.15, 700.0, 999.0])
+    ang = np.array([90.0, 1.0, 179.0])
+    m = sp.get_model("R24")
+    for policy in (1, 2):
+        gpu_ctx.set_kernel_policy(policy)
+        try:
+            tb, valid = gpu_ctx.tb_batch(m, z, p, t, rh, frq, ang)
+        finally:
+            gpu_ctx.set_kernel_policy(0)
+        ref, vref = c_oracle.tb_batch(m, z, p, t, rh, frq, ang)
+        assert np.array_equal(valid, vref)
+        ok = valid == 1
+        assert ok.sum() >= nprof - 2
+        fin = np.isfinite(ref[ok])
+        assert np.array_equal(np.isfinite(tb[ok]), fin)
+        # opaque slant paths through 340-K air at 999 GHz are fine; tolerance stays the same 1e-6 K
+        assert np.abs(tb[ok][fin] - ref[ok][fin]).max() <= TOL_K, policy
