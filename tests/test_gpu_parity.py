@@ -690,3 +690,27 @@ def test_config5_full_per_gpu_share(gpu_ctx):
     sub = np.arange(5, 1000, 83)
     r = c_oracle.tb_profile(sp.get_model("R24"), P["z"][777], P["p"][777], P["t"][777], P["rh"][777], frq[sub], ang)
     assert np.abs(tb[777][:, sub] - r["tbtotal"].reshape(7, len(sub))).max() <= TOL_K
+
+
+def test_sharded_entry_over_rccl_single_rank(gpu_ctx):
+    """distributed.tb_batch_sharded on the real backend ("nccl" = RCCL) with the one rank a 1-GPU box
+    has: the gather path runs on device tensors and must return exactly the direct result."""
+    import socket
+    import torch
+    import torch.distributed as dist
+    from mwr_fast_forward_operators_and_lbls_amd.distributed import tb_batch_sharded
+    P = pr.synthetic_profiles(33, 83)
+    P["p"][5, 0] = np.nan
+    direct, vdirect = gpu_ctx.tb_batch("R24", P["z"], P["p"], P["t"], P["rh"], pr.HATPRO_FRQS, pr.BENCH_ELEVATIONS_7)
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1,
+                            device_id=torch.device("cuda", 0))
+    try:
+        tb, valid = tb_batch_sharded("R24", P["z"], P["p"], P["t"], P["rh"], pr.HATPRO_FRQS, pr.BENCH_ELEVATIONS_7)
+    finally:
+        dist.destroy_process_group()
+    assert np.array_equal(valid, vdirect) and valid[5] == 0
+    assert np.array_equal(np.nan_to_num(tb), np.nan_to_num(direct))
