@@ -714,3 +714,27 @@ def test_sharded_entry_over_rccl_single_rank(gpu_ctx):
         dist.destroy_process_group()
     assert np.array_equal(valid, vdirect) and valid[5] == 0
     assert np.array_equal(np.nan_to_num(tb), np.nan_to_num(direct))
+
+
+def test_minimal_ctypes_binding_as_documented(native_lib):
+    """INTEGRATION.md section 3, executed: a bare ctypes binding of the C ABI with no help from _native.Context."""
+    import ctypes
+    from mwr_fast_forward_operators_and_lbls_amd import _native
+    lib = ctypes.CDLL(_native.LIB_PATH)
+    lib.mwrt_last_error.restype = ctypes.c_char_p
+    ctx, mdl = ctypes.c_void_p(), ctypes.c_void_p()
+    assert lib.mwrt_create(0, ctypes.byref(ctx)) == 0
+    desc = sp.get_model("R24").to_c()
+    assert lib.mwrt_model_create(ctx, ctypes.byref(desc), ctypes.byref(mdl)) == 0
+    Pf = pr.synthetic_profiles(3, 84)
+    z, p, t, rh = (np.ascontiguousarray(Pf[k]) for k in ("z", "p", "t", "rh"))
+    frq, elev = pr.HATPRO_FRQS.copy(), np.array([90.0, 30.0])
+    nprof, nlev, nf, nang = 3, 180, 14, 2
+    tb = np.empty((nprof, nang, nf)); valid = np.empty(nprof, np.uint8)
+    P = lambda a: a.ctypes.data_as(ctypes.c_void_p)      # noqa: E731
+    rc = lib.mwrt_tb_batch(ctx, mdl, ctypes.c_int64(nprof), nlev, P(z), P(p), P(t), P(rh),
+                           nf, P(frq), nang, P(elev), P(tb), P(valid), None)
+    assert rc == 0, lib.mwrt_last_error().decode()
+    ref = lo.tb_cloud_rte(sp.get_model("R24"), z[2], p[2], t[2], rh[2], frq, elev)["tbtotal"]
+    assert valid.tolist() == [1, 1, 1] and np.abs(tb[2].ravel() - ref).max() <= TOL_K
+    assert lib.mwrt_model_destroy(ctx, mdl) == 0 and lib.mwrt_destroy(ctx) == 0
