@@ -25,6 +25,32 @@
  *   valid_out  [nprof] 1 = ok; 0 = NaN in the inputs of that profile (the wrapper's
  *              check_for_nans, :71-79, :117-119: outputs stay NaN); 2 = negative absorption
  *              met in the layer integration (pyrtlib raises ValueError there).
+ *
+ * NaN rules (check_for_nans is evaluated per (time, Crop, elevation), :101-119):
+ *   NaN in a profile's z/p/T/rh   -> that profile's outputs NaN, valid = 0;
+ *   NaN in elev_deg[k]            -> only the [:, k, :] rows are NaN (the reference skips that k
+ *                                    alone, :106, :117); the other angles are computed and valid
+ *                                    stays 1 -- valid describes the profile's own data;
+ *   NaN in frq_ghz (or every elevation NaN) -> every output NaN, valid = 0 (frqs is shared by all
+ *                                    calls of the wrapper, :87-88).
+ *
+ * Reproducibility: results are deterministic for a given call.  The kernels process the
+ * frequencies in chunks (14 or 16 per workgroup) and choose per chunk between algebraically
+ * equal forms of a line's denominator (polynomial in f^2 away from line centres, direct
+ * detunings next to them), so the TB of one frequency may differ by <= 1e-8 K depending on
+ * which other frequencies share its call.  Against the 1e-6 K parity bar this is invisible.
+ *
+ * Streams: the *_device entry points are asynchronous on `stream`:
+ *   NULL               the context's own stream (hipStreamNonBlocking: NOT ordered with the
+ *                      legacy default stream -- synchronise with mwrt_synchronize(ctx, NULL));
+ *   MWRT_STREAM_LEGACY the caller's legacy default stream (hipStream_t 0, what
+ *                      torch.cuda.current_stream().cuda_stream reads as 0);
+ *   anything else      that hipStream_t.
+ * Work is ordered on that stream like any kernel launch; consumers on other streams need an
+ * event.  frq_ghz / elev_deg are host arrays: the first call with new values makes an immutable
+ * device copy (a short host-side wait on the context's stream); later calls with the same values
+ * neither allocate nor synchronise, which is what makes the call hipGraph-capturable after one
+ * warm-up call.
  */
 #ifndef MWRT_H
 #define MWRT_H
@@ -41,6 +67,7 @@ extern "C" {
 #define MWRT_MAX_O2_LINES 64
 #define MWRT_MAX_LEVELS 1024      /* one lane per level, one workgroup per profile */
 #define MWRT_MAX_ANGLES 64
+#define MWRT_STREAM_LEGACY ((void*)(intptr_t)-1)   /* `stream` value meaning hipStream_t 0 */
 
 typedef enum {
   MWRT_OK = 0,
@@ -116,8 +143,8 @@ int mwrt_tb_batch(mwrt_context* ctx, const mwrt_model* model,
                   double* tb_out, uint8_t* valid_out, const mwrt_tb_extras* extras);
 
 /* Same, on DEVICE buffers (profiles, tb_out, valid_out and the extras already in HBM),
- * asynchronous on `stream` (a hipStream_t; NULL = the context's own stream).  frq_ghz and
- * elev_deg stay small host arrays.  This is the entry bench.py times. */
+ * asynchronous on `stream` (a hipStream_t; NULL / MWRT_STREAM_LEGACY: see "Streams" above).
+ * frq_ghz and elev_deg stay small host arrays.  This is the entry bench.py times. */
 int mwrt_tb_batch_device(mwrt_context* ctx, const mwrt_model* model,
                          int64_t nprof, int32_t nlev,
                          const double* d_z_km, const double* d_p_hpa, const double* d_t_k,

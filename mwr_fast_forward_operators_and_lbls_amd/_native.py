@@ -134,6 +134,23 @@ def _ptr(x):
     return x.ctypes.data_as(ctypes.c_void_p) if isinstance(x, np.ndarray) else ctypes.c_void_p(int(x))
 
 
+#: include/mwrt.h MWRT_STREAM_LEGACY: the caller's legacy default stream (hipStream_t 0)
+STREAM_LEGACY = ctypes.c_void_p(-1).value
+
+
+def _stream(stream):
+    """`stream` argument of the *_device entry points -> the ABI's void*.
+
+    None = the context's own non-blocking stream (ABI NULL); 0 = the legacy default stream --
+    what ``torch.cuda.current_stream().cuda_stream`` returns for torch's default stream -- passed
+    as MWRT_STREAM_LEGACY so the launch is ordered with the caller's other default-stream work;
+    any other integer is a hipStream_t handle."""
+    if stream is None:
+        return None
+    stream = int(stream)
+    return ctypes.c_void_p(STREAM_LEGACY if stream == 0 else stream)
+
+
 def _serialised(method):
     """A native context owns one workspace and one stream: calls from several Python threads are
     serialised per context (ctypes drops the GIL during the call)."""
@@ -157,8 +174,10 @@ class Context:
         self._check(self._lib.mwrt_create(int(device_id), ctypes.byref(h)), "mwrt_create")
         self._handle = h
         self.device_id = int(device_id)
-        self._models: Dict[str, ctypes.c_void_p] = {}
-        self._model_tables: Dict[str, ModelTables] = {}
+        # device tables per ModelTables OBJECT (keyed by identity, the record kept alive beside its
+        # handle): two different records may share a name, and a handle is never destroyed while
+        # the context lives -- a queued launch or another caller may still hold it
+        self._models: Dict[int, tuple] = {}
 
     # -- plumbing ---------------------------------------------------------------------------
     def _check(self, rc: int, where: str):
@@ -168,7 +187,7 @@ class Context:
     @_serialised
     def close(self):
         if getattr(self, "_handle", None):
-            for m in self._models.values():
+            for m, _tables in self._models.values():
                 self._lib.mwrt_model_destroy(self._handle, m)
             self._models.clear()
             self._lib.mwrt_destroy(self._handle)
@@ -190,16 +209,13 @@ class Context:
     def model(self, model) -> ctypes.c_void_p:
         """Device-resident tables for a model name or a ModelTables record (cached per context)."""
         tables = get_model(model) if isinstance(model, str) else model
-        key = tables.name
-        if key in self._models and self._model_tables[key] is tables:
-            return self._models[key]
-        if key in self._models:
-            self._lib.mwrt_model_destroy(self._handle, self._models.pop(key))
+        hit = self._models.get(id(tables))
+        if hit is not None:
+            return hit[0]
         desc = tables.to_c()
         h = ctypes.c_void_p()
         self._check(self._lib.mwrt_model_create(self._handle, ctypes.byref(desc), ctypes.byref(h)), "mwrt_model_create")
-        self._models[key] = h
-        self._model_tables[key] = tables
+        self._models[id(tables)] = (h, tables)
         return h
 
     # -- host-buffer entry points ------------------------------------------------------------
@@ -244,13 +260,13 @@ class Context:
         return tb, valid
 
     @_serialised
-    def tb_batch_multi_device(self, models, nprof, nlev, d_z, d_p, d_t, d_rh, frq, elev, d_tb, d_valid, stream: int = 0):
+    def tb_batch_multi_device(self, models, nprof, nlev, d_z, d_p, d_t, d_rh, frq, elev, d_tb, d_valid, stream=None):
         frq, elev = _f64(frq).ravel(), _f64(elev).ravel()
         handles = (ctypes.c_void_p * len(models))(*[self.model(m) for m in models])
         self._check(self._lib.mwrt_tb_batch_multi_device(
             self._handle, len(models), handles, int(nprof), int(nlev), _ptr(d_z), _ptr(d_p), _ptr(d_t), _ptr(d_rh),
             frq.size, _ptr(frq), elev.size, _ptr(elev), _ptr(d_tb), _ptr(d_valid),
-            ctypes.c_void_p(stream) if stream else None), "mwrt_tb_batch_multi_device")
+            _stream(stream)), "mwrt_tb_batch_multi_device")
 
     @_serialised
     def absorption_batch(self, model, p, t, rh, frq):
@@ -269,21 +285,21 @@ class Context:
     # -- device-buffer entry points (raw device addresses, e.g. torch.Tensor.data_ptr()) -------
     @_serialised
     def tb_batch_device(self, model, nprof, nlev, d_z, d_p, d_t, d_rh, frq, elev, d_tb, d_valid,
-                        extras: Optional[MwrtTbExtras] = None, stream: int = 0):
+                        extras: Optional[MwrtTbExtras] = None, stream=None):
         frq, elev = _f64(frq).ravel(), _f64(elev).ravel()
         self._check(self._lib.mwrt_tb_batch_device(
             self._handle, self.model(model), int(nprof), int(nlev), _ptr(d_z), _ptr(d_p), _ptr(d_t), _ptr(d_rh),
             frq.size, _ptr(frq), elev.size, _ptr(elev), _ptr(d_tb), _ptr(d_valid),
             ctypes.byref(extras) if extras is not None else None,
-            ctypes.c_void_p(stream) if stream else None), "mwrt_tb_batch_device")
+            _stream(stream)), "mwrt_tb_batch_device")
 
     @_serialised
-    def absorption_batch_device(self, model, nprof, nlev, d_p, d_t, d_rh, frq, d_awet, d_adry, stream: int = 0):
+    def absorption_batch_device(self, model, nprof, nlev, d_p, d_t, d_rh, frq, d_awet, d_adry, stream=None):
         frq = _f64(frq).ravel()
         self._check(self._lib.mwrt_absorption_batch_device(
             self._handle, self.model(model), int(nprof), int(nlev), _ptr(d_p), _ptr(d_t), _ptr(d_rh),
             frq.size, _ptr(frq), _ptr(d_awet), _ptr(d_adry),
-            ctypes.c_void_p(stream) if stream else None), "mwrt_absorption_batch_device")
+            _stream(stream)), "mwrt_absorption_batch_device")
 
     @_serialised
     def set_kernel_policy(self, policy: int):
@@ -300,9 +316,8 @@ class Context:
         return outs
 
     @_serialised
-    def synchronize(self, stream: int = 0):
-        self._check(self._lib.mwrt_synchronize(self._handle, ctypes.c_void_p(stream) if stream else None),
-                    "mwrt_synchronize")
+    def synchronize(self, stream=None):
+        self._check(self._lib.mwrt_synchronize(self._handle, _stream(stream)), "mwrt_synchronize")
 
     @_serialised
     def set_timing(self, enabled: bool):

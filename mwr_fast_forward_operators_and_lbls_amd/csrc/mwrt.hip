@@ -42,6 +42,44 @@ struct DevBuf {
   template <class T> T* as() { return static_cast<T*>(p); }
 };
 
+// Content-keyed, immutable device copies of small host arrays.
+struct ParamCache {
+  struct Entry { std::vector<double> host; double* dev = nullptr; unsigned long stamp = 0; };
+  std::vector<Entry> entries;
+  unsigned long clock = 0;
+  static constexpr size_t MAX_ENTRIES = 32;
+  // device pointer holding exactly src[0..n); uploads through `copy_stream` (never a capturing stream)
+  hipError_t get(const double* src, int n, hipStream_t copy_stream, const double** out) {
+    for (Entry& e : entries)
+      if ((int)e.host.size() == n && std::memcmp(e.host.data(), src, sizeof(double) * (size_t)n) == 0) {
+        e.stamp = ++clock; *out = e.dev; return hipSuccess;
+      }
+    if (entries.size() >= MAX_ENTRIES) {
+      // evict the least recently used copy -- only after everything queued on the device has drained
+      hipError_t e = hipDeviceSynchronize();
+      if (e != hipSuccess) return e;
+      size_t lru = 0;
+      for (size_t i = 1; i < entries.size(); ++i) if (entries[i].stamp < entries[lru].stamp) lru = i;
+      (void)hipFree(entries[lru].dev);
+      entries.erase(entries.begin() + (long)lru);
+    }
+    Entry ne;
+    ne.host.assign(src, src + n);
+    hipError_t e = hipMalloc((void**)&ne.dev, sizeof(double) * (size_t)(n > 0 ? n : 1));
+    if (e != hipSuccess) return e;
+    // a fresh buffer nobody reads yet: copy on the context's own stream and wait for it, so the
+    // bytes are in HBM before any stream (the caller's included) can launch a reader
+    e = hipMemcpyAsync(ne.dev, ne.host.data(), sizeof(double) * (size_t)n, hipMemcpyHostToDevice, copy_stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(copy_stream);
+    if (e != hipSuccess) { (void)hipFree(ne.dev); return e; }
+    ne.stamp = ++clock;
+    entries.push_back(std::move(ne));
+    *out = entries.back().dev;
+    return hipSuccess;
+  }
+  void release() { for (Entry& e : entries) (void)hipFree(e.dev); entries.clear(); }
+};
+
 }  // namespace
 
 struct mwrt_context {
@@ -49,9 +87,10 @@ struct mwrt_context {
   hipStream_t stream = nullptr;
   int lds_max = 65536;
   int kernel_policy = 0;        // 0 auto, 1 fused, 2 spectral
-  // small per-call parameter arrays (frq, airmass) cached on the device by content
-  DevBuf d_frq, d_am;
-  std::vector<double> h_frq, h_am;
+  // small per-call parameter arrays (frq, airmass): content-keyed device copies.  A copy is never
+  // overwritten or freed while the context lives (bar LRU eviction behind a device-wide drain), so
+  // launches still queued on ANY stream and captured hipGraphs keep reading valid memory.
+  ParamCache frq_cache, am_cache;
   // staging for the host-buffer entry points
   DevBuf d_in, d_out, d_valid, d_ex;
   // timing: a ring of hipEvent pairs recorded around every kernel launch, on the launch stream
@@ -101,16 +140,17 @@ size_t fused_lds_bytes(int nfc, const LaunchGeom& g, int nang, int threads) {
 // K2 split for a chunk width, shrunk until the workgroup's LDS fits; false if it cannot
 bool plan_fused(const mwrt_context* c, int nfc, int nlev, int nf, int nang, LaunchGeom* g, size_t* lds);
 
-int upload_small(mwrt_context* c, DevBuf& buf, std::vector<double>& cache, const double* src, int n,
-                 hipStream_t st) {
-  if ((int)cache.size() == n && std::memcmp(cache.data(), src, sizeof(double) * n) == 0 && buf.p) return MWRT_OK;
-  // the previous contents may still be read by queued kernels: drain before overwriting
-  HIP_TRY(hipStreamSynchronize(st));
-  if (c->stream != st) HIP_TRY(hipStreamSynchronize(c->stream));
-  HIP_TRY(buf.reserve(sizeof(double) * (size_t)n));
-  cache.assign(src, src + n);
-  HIP_TRY(hipMemcpy(buf.p, cache.data(), sizeof(double) * n, hipMemcpyHostToDevice));
+int upload_small(mwrt_context* c, ParamCache& cache, const double* src, int n, const double** dev) {
+  HIP_TRY(cache.get(src, n, c->stream, dev));
   return MWRT_OK;
+}
+
+// `stream` argument of the *_device entry points: NULL = the context's own (non-blocking) stream,
+// MWRT_STREAM_LEGACY = the caller's legacy default stream (hipStream_t 0), else the handle itself
+hipStream_t resolve_stream(const mwrt_context* c, void* stream) {
+  if (!stream) return c->stream;
+  if (stream == MWRT_STREAM_LEGACY) return (hipStream_t) nullptr;
+  return (hipStream_t)stream;
 }
 
 int check_common(const mwrt_context* c, const mwrt_model* m, int64_t nprof, int32_t nlev, int32_t nf) {
@@ -275,7 +315,7 @@ int mwrt_destroy(mwrt_context* c) {
   if (!c) return MWRT_OK;
   (void)hipSetDevice(c->device);
   (void)hipStreamSynchronize(c->stream);
-  c->d_frq.release(); c->d_am.release(); c->d_in.release(); c->d_out.release();
+  c->frq_cache.release(); c->am_cache.release(); c->d_in.release(); c->d_out.release();
   c->d_valid.release(); c->d_ex.release();
   for (hipEvent_t e : c->ev0) (void)hipEventDestroy(e);
   for (hipEvent_t e : c->ev1) (void)hipEventDestroy(e);
@@ -342,11 +382,14 @@ static int tb_launch(mwrt_context* c, int nmodels, const mwrt_model* const* ms, 
   const int64_t rows = nprof * nmodels;
   if (rows > 2147483647LL) return fail(MWRT_ERR_UNSUPPORTED, "nmodels x nprof exceeds grid limit");
   HIP_TRY(hipSetDevice(c->device));
-  hipStream_t st = stream ? (hipStream_t)stream : c->stream;
+  hipStream_t st = resolve_stream(c, stream);
   if (nprof == 0) return MWRT_OK;
   const size_t nout = (size_t)rows * nang * nf;
-  if (any_nan(frq, nf) || any_nan(elev, nang)) {
-    // check_for_nans covers frqs and ang too (PyRTlib_processing.py:77-78): everything stays NaN
+  bool all_elev_nan = true;
+  for (int a = 0; a < nang; ++a) all_elev_nan = all_elev_nan && std::isnan(elev[a]);
+  if (any_nan(frq, nf) || all_elev_nan) {
+    // check_for_nans covers frqs and ang too (PyRTlib_processing.py:77-78): a NaN frequency (the
+    // wrapper's frqs array is shared by every call) leaves everything NaN, valid = 0
     HIP_TRY(hipMemsetAsync(d_tb, 0xFF, nout * sizeof(double), st));
     HIP_TRY(hipMemsetAsync(d_valid, 0, (size_t)rows, st));
     if (ex) {
@@ -360,13 +403,19 @@ static int tb_launch(mwrt_context* c, int nmodels, const mwrt_model* const* ms, 
   }
   std::vector<double> am(nang);
   for (int a = 0; a < nang; ++a) {
+    // The wrapper tests ang = [elevation_k] per k (PyRTlib_processing.py:106, :117) and skips only that
+    // k: a NaN elevation blanks its own [:, k, :] rows and nothing else.  Its air mass is NaN, which
+    // the slant-path integration carries into every output of that angle; valid[] is about the
+    // profile's own data and stays 1.
+    if (std::isnan(elev[a])) { am[a] = std::nan(""); continue; }
     // plane-parallel air mass 1/sin(elev); a path at or below the horizon has none
     if (!(elev[a] > 0.0 && elev[a] < 180.0))
       return fail(MWRT_ERR_INVALID_ARGUMENT, "elevation angles must lie in (0, 180) degrees");
     am[a] = 1.0 / std::sin(elev[a] * M_PI / 180.0);
   }
-  int rc = upload_small(c, c->d_frq, c->h_frq, frq, nf, st); if (rc) return rc;
-  rc = upload_small(c, c->d_am, c->h_am, am.data(), nang, st); if (rc) return rc;
+  const double *dev_frq = nullptr, *dev_am = nullptr;
+  int rc = upload_small(c, c->frq_cache, frq, nf, &dev_frq); if (rc) return rc;
+  rc = upload_small(c, c->am_cache, am.data(), nang, &dev_am); if (rc) return rc;
 
   // automatic = fused: measured on MI355X the spectral kernel loses to it even on the 1000-frequency
   // grid (profiles/r01_finegrid.txt), so it stays opt-in until it wins
@@ -375,7 +424,7 @@ static int tb_launch(mwrt_context* c, int nmodels, const mwrt_model* const* ms, 
     if (nmodels != 1) return fail(MWRT_ERR_UNSUPPORTED, "the spectral kernel evaluates one model per launch");
     SpectralArgs sa{};
     sa.M = ms[0]->d_desc; sa.z = d_z; sa.p = d_p; sa.t = d_t; sa.rh = d_rh;
-    sa.frq = c->d_frq.as<double>(); sa.airmass = c->d_am.as<double>();
+    sa.frq = dev_frq; sa.airmass = dev_am;
     sa.tb = d_tb; sa.valid = d_valid;
     if (ex) { sa.tbatm = ex->tbatm; sa.tmr = ex->tmr; sa.tauwet = ex->tauwet; sa.taudry = ex->taudry; sa.taulay = ex->taulay; }
     sa.nlev = nlev; sa.nf = nf; sa.nang = nang;
@@ -385,7 +434,7 @@ static int tb_launch(mwrt_context* c, int nmodels, const mwrt_model* const* ms, 
   for (int i = 0; i < nmodels; ++i) a.Ms[i] = ms[i]->d_desc;
   a.nprof_in = nprof;
   a.z = d_z; a.p = d_p; a.t = d_t; a.rh = d_rh;
-  a.frq = c->d_frq.as<double>(); a.airmass = c->d_am.as<double>();
+  a.frq = dev_frq; a.airmass = dev_am;
   a.tb = d_tb; a.valid = d_valid;
   if (ex) { a.tbatm = ex->tbatm; a.tmr = ex->tmr; a.tauwet = ex->tauwet; a.taudry = ex->taudry; a.taulay = ex->taulay; }
   a.nlev = nlev; a.nf = nf; a.nang = nang;
@@ -508,11 +557,12 @@ int mwrt_absorption_batch_device(mwrt_context* c, const mwrt_model* m, int64_t n
   if (!d_p || !d_t || !d_rh || !frq || !d_awet || !d_adry) return fail(MWRT_ERR_INVALID_ARGUMENT, "null buffer");
   if (any_nan(frq, nf)) return fail(MWRT_ERR_INVALID_ARGUMENT, "NaN frequency");
   HIP_TRY(hipSetDevice(c->device));
-  hipStream_t st = stream ? (hipStream_t)stream : c->stream;
+  hipStream_t st = resolve_stream(c, stream);
   if (nprof == 0) return MWRT_OK;
-  rc = upload_small(c, c->d_frq, c->h_frq, frq, nf, st); if (rc) return rc;
+  const double* dev_frq = nullptr;
+  rc = upload_small(c, c->frq_cache, frq, nf, &dev_frq); if (rc) return rc;
   AbsorbArgs a{};
-  a.M = m->d_desc; a.p = d_p; a.t = d_t; a.rh = d_rh; a.frq = c->d_frq.as<double>();
+  a.M = m->d_desc; a.p = d_p; a.t = d_t; a.rh = d_rh; a.frq = dev_frq;
   a.awet = d_awet; a.adry = d_adry; a.nlev = nlev; a.nf = nf;
   switch (pick_nfc(nf)) {
     case 8: return launch_absorb<8>(c, a, nprof, st);
@@ -577,7 +627,7 @@ int mwrt_selftest_math(mwrt_context* c, int32_t n, const double* x, const double
 int mwrt_synchronize(mwrt_context* c, void* stream) {
   if (!c) return fail(MWRT_ERR_INVALID_ARGUMENT, "null context");
   HIP_TRY(hipSetDevice(c->device));
-  HIP_TRY(hipStreamSynchronize(stream ? (hipStream_t)stream : c->stream));
+  HIP_TRY(hipStreamSynchronize(resolve_stream(c, stream)));
   return MWRT_OK;
 }
 

@@ -10,6 +10,7 @@ ROCm, riding xGMI; "gloo" in the CPU tests).  Payloads are tiny against xGMI (co
 """
 from __future__ import annotations
 
+import os
 from typing import Optional, Tuple
 
 import numpy as np
@@ -23,6 +24,21 @@ def shard_bounds(nprof: int, world_size: int, rank: int) -> Tuple[int, int]:
     per = -(-nprof // world_size)
     lo = min(rank * per, nprof)
     return lo, min(lo + per, nprof)
+
+
+def local_device_id(device_id: Optional[int] = None) -> int:
+    """GPU of this rank: explicit ``device_id`` > ``LOCAL_RANK`` > torch's current device > 0."""
+    if device_id is not None:
+        return int(device_id)
+    if os.environ.get("LOCAL_RANK", "") != "":
+        return int(os.environ["LOCAL_RANK"])
+    try:
+        import torch
+        if torch.cuda.is_available():
+            return int(torch.cuda.current_device())
+    except ImportError:
+        pass
+    return 0
 
 
 def gather_shards(local, nprof_total: int, group=None):
@@ -51,7 +67,12 @@ def tb_batch_sharded(model, z, p, t, rh, frq, ang, group=None, device_id: Option
     Each rank computes its contiguous block with the HIP library on its own GPU and the blocks
     are gathered once.  Returns ``(tb [nprof][nang][nf], valid [nprof])`` as NumPy arrays on
     every rank.  ``gather_device`` is where the result shards sit for the collective: the rank's
-    GPU (default; RCCL needs device tensors) or ``torch.device("cpu")`` under the gloo backend."""
+    GPU (default; RCCL needs device tensors) or ``torch.device("cpu")`` under the gloo backend.
+
+    The rank's GPU is ``device_id`` if given, else ``LOCAL_RANK`` (what torchrun exports), else
+    torch's current device; it is made torch's current device before the context and the gather
+    tensors are created, so a plain ``torchrun script.py`` puts rank r on GPU r without the
+    script calling ``torch.cuda.set_device`` itself."""
     import torch
     import torch.distributed as dist
 
@@ -63,8 +84,9 @@ def tb_batch_sharded(model, z, p, t, rh, frq, ang, group=None, device_id: Option
     ang = np.asarray(ang, dtype=np.float64)
     nf, nang = len(frq), len(ang)
     from . import _native
-    if device_id is None:
-        device_id = torch.cuda.current_device() if gather_device is None else 0
+    device_id = local_device_id(device_id)
+    if gather_device is None:
+        torch.cuda.set_device(device_id)
     dev = gather_device if gather_device is not None else torch.device("cuda", device_id)
     if hi > lo:
         sl = slice(lo, hi)

@@ -79,13 +79,18 @@ def pack_profiles(ds):
     return z, p, t, rh, ntime, ncrop
 
 
-def _attrs(tag):
-    return {
+def _attrs(tag, tables=None):
+    a = {
         'long_name': f'Brightness temperature modelled by {tag}',
         'units': 'K',
         'standard_name': 'brightness_temperature',
         'comments': 'Brightness temperatures modeled from radiosonde data for 14 channels of HATPRO radiometer',
     }
+    if tables is not None:
+        # not in the reference (:162-168): which spectroscopic tables actually produced the numbers
+        a['tables_provenance'] = tables.provenance
+        a['tables_parity'] = tables.parity + (f" (alias of {tables.alias_of})" if tables.alias_of else "")
+    return a
 
 
 def derive_TBs4PyRTlib(ds, args=None):
@@ -112,14 +117,19 @@ def derive_TBs4PyRTlib(ds, args=None):
         # [nprof][nang][nf] -> (time, nf, nang, Crop); profiles were packed time-major, Crop-minor
         out = tb.reshape(ntime, ncrop, nang, nf).transpose(0, 3, 2, 1)
         results[suffix] = np.ascontiguousarray(out)
-    nbad = int((valid == 0).sum())
-    for _ in range(nbad * nang):
-        print("NaNs found!!!!!!!")       # reference :153-154 prints once per (time, Crop, elevation)
+    # reference :117-119, :153-154: one message per (time, Crop, elevation) whose inputs hold a NaN --
+    # a NaN profile counts for every elevation, a NaN elevation for every profile
+    bad_prof = valid == 0
+    nan_ang = np.isnan(ang)
+    nbad = int(np.count_nonzero(bad_prof[:, None] | nan_ang[None, :])) if not np.isnan(frqs).any() else nprof * nang
+    for _ in range(nbad):
+        print("NaNs found!!!!!!!")
 
+    by_suffix = {suffix: tables[k] for k, (suffix, _) in enumerate(MODEL_RUNS)}
     for tag in ("R24", "R17", "R98", "R20"):          # reference assignment order :161-195
         name = "TBs_PyRTlib_" + tag
         ds[name] = (('time', 'N_Channels', 'elevation', 'Crop'), results[tag])
-        ds[name].attrs = _attrs(tag)
+        ds[name].attrs = _attrs(tag, by_suffix[tag])
     return ds
 
 

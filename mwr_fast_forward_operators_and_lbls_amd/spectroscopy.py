@@ -36,7 +36,8 @@ from __future__ import annotations
 import ctypes
 import dataclasses
 import json
-from typing import Dict
+import warnings
+from typing import Dict, Optional
 
 import numpy as np
 
@@ -95,6 +96,10 @@ class ModelTables:
     t_cosmic: float = 2.736
     planck_h: float = 6.6260755e-34
     boltzmann_k: float = 1.380658e-23
+    # ---- provenance (host-side only; not part of mwrt_model_desc) ----
+    alias_of: Optional[str] = None   # set when this NAME is served by another model's tables
+    parity: str = "unpinned"         # "unpinned": restated from the literature; "exported": dumped from an
+    #                                  installed pyrtlib by tools/export_pyrtlib_tables.py
 
     H2O_KEYS = ("fl", "s1", "b2", "w0", "x", "w0s", "xs", "sh", "xh", "shs", "xhs",
                 "aair", "aself", "w2", "xw2", "w2s", "xw2s", "d2", "d2s")
@@ -127,7 +132,9 @@ class ModelTables:
 
     @classmethod
     def from_json(cls, text: str) -> "ModelTables":
-        return cls(**json.loads(text))
+        """Keys starting with "_" are annotations of the exporting tool (e.g. which scalar switches it
+        could not read from pyrtlib) and are not part of the record."""
+        return cls(**{k: v for k, v in json.loads(text).items() if not k.startswith("_")})
 
     def to_c(self) -> "MwrtModelDesc":
         c = MwrtModelDesc()
@@ -461,7 +468,7 @@ _register(dataclasses.replace(
     h2o=_copy(_H2O_SD), o2=_copy(_O2_R20)))
 
 _register(dataclasses.replace(
-    _MODELS["R20SD"], name="R24",
+    _MODELS["R20SD"], name="R24", alias_of="R20SD",
     provenance="carried as the R20SD parameter family: the 2021-2024 revisions in pyrtlib's R24 could not "
                "be restated offline -- UNPINNED, replace via tools/export_pyrtlib_tables.py",
     h2o=_copy(_H2O_SD), o2=_copy(_O2_R20)))
@@ -476,13 +483,25 @@ def implemented_models():
     return sorted(_MODELS)
 
 
+_warned_aliases = set()
+
+
 def get_model(name: str) -> ModelTables:
-    """Tables for ``name``; raises ValueError like pyrtlib does for an unknown model string."""
+    """Tables for ``name``; raises ValueError like pyrtlib does for an unknown model string.
+
+    A name that is served by ANOTHER model's tables (today: "R24", carried as the R20SD family)
+    raises a one-time ``UserWarning`` per process, so nobody reads TBs labelled R24 as pyrtlib's R24."""
     try:
-        return _MODELS[name]
+        m = _MODELS[name]
     except KeyError:
         raise ValueError(
             f"Model {name!r} not available. Implemented: {implemented_models()}") from None
+    if m.alias_of and name not in _warned_aliases:
+        _warned_aliases.add(name)
+        warnings.warn(f"{name} carried as {m.alias_of} tables -- parity vs pyrtlib unpinned "
+                      f"(install real tables with tools/export_pyrtlib_tables.py + register_model)",
+                      UserWarning, stacklevel=2)
+    return m
 
 
 def register_model(tables: ModelTables, overwrite: bool = False):

@@ -68,19 +68,22 @@ def oracle_engine(tables, z, p, t, rh, frq, ang):
     valid = np.ones(nprof, dtype=np.uint8)
     ex = {k: np.full((nprof, nang, nf), np.nan) for k in ("tbatm", "tmr", "tauwet", "taudry")}
     ex["taulay"] = np.full((nprof, nf, z.shape[1]), np.nan)
-    bad_global = np.isnan(frq).any() or np.isnan(ang).any()
+    # check_for_nans is evaluated per (time, Crop, elevation) (PyRTlib_processing.py:101-119): a NaN
+    # elevation blanks its own rows only; a NaN frequency (shared by every call) blanks everything
+    good = ~np.isnan(ang)
+    bad_global = np.isnan(frq).any() or not good.any()
     for i in range(nprof):
         if bad_global or any(np.isnan(a[i]).any() for a in (z, p, t, rh)):
             valid[i] = 0
             continue
         try:
-            r = lbl_oracle.tb_cloud_rte(tables, z[i], p[i], t[i], rh[i], frq, ang)
+            r = lbl_oracle.tb_cloud_rte(tables, z[i], p[i], t[i], rh[i], frq, ang[good])
         except ValueError:
             valid[i] = 2
             continue
-        tb[i] = r["tbtotal"].reshape(nang, nf)
+        tb[i, good] = r["tbtotal"].reshape(-1, nf)
         for k in ("tbatm", "tmr", "tauwet", "taudry"):
-            ex[k][i] = r[k].reshape(nang, nf)
-        zen = r["taulay"][:, 0, :] * np.sin(ang[0] * np.pi / 180)
+            ex[k][i, good] = r[k].reshape(-1, nf)
+        zen = r["taulay"][:, 0, :] * np.sin(ang[good][0] * np.pi / 180)
         ex["taulay"][i] = zen
     return tb, valid, ex

@@ -71,3 +71,29 @@ def test_export_roundtrip_with_fake_pyrtlib(monkeypatch):
                     "o2_nonres", "o2_coef", "n2_l", "n2_m", "n2_n", "n2_fdep", "n2_ptot", "h2o_cf", "h2o_cs", "o2_x"):
             assert getattr(back, fld) == getattr(src, fld), (name, fld)
         json.loads(buf.getvalue())
+
+
+def test_export_overrides_and_unverified_list(monkeypatch):
+    """Every scalar switch can be overridden; the hard-coded ones are listed as unverified; an O2
+    post-scale is folded into o2_coef (importing line lists cannot fix a wrong scalar)."""
+    spec = importlib.util.spec_from_file_location("export_tool", os.path.join(ROOT, "tools", "export_pyrtlib_tables.py"))
+    tool = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(tool)
+    src = sp.get_model("R20")
+    for k, v in fake_pyrtlib(src).items():
+        monkeypatch.setitem(sys.modules, k, v)
+    buf = io.StringIO()
+    with redirect_stdout(buf):
+        tool.main("R20", sets=["o2_wv_factor=1.25", "n2_fdep=0"], o2_post_scale=1.004)
+    raw = json.loads(buf.getvalue())
+    assert "o2_coef" in raw["_unverified_scalars"] and "o2_wv_factor" not in raw["_unverified_scalars"]
+    assert "n2_fdep" not in raw["_unverified_scalars"] and "h2o_cf" not in raw["_unverified_scalars"]
+    back = sp.ModelTables.from_json(buf.getvalue())
+    assert back.o2_wv_factor == 1.25 and back.n2_fdep == 0 and isinstance(back.n2_fdep, int)
+    assert back.o2_coef == src.o2_coef * 1.004
+    assert back.parity == "exported" and back.alias_of is None
+    import pytest
+    with pytest.raises(SystemExit):
+        tool.apply_overrides(dict(raw), ["h2o=3"])
+    with pytest.raises(SystemExit):
+        tool.apply_overrides(dict(raw), ["no_such_field=3"])

@@ -104,7 +104,8 @@ def test_two_level_profile_and_limits(gpu_ctx):
 
 def test_nan_in_nan_out(gpu_ctx):
     """check_for_nans contract (PyRTlib_processing.py:71-79, :117-119): a NaN anywhere in a profile
-    leaves that profile's TBs NaN and touches nobody else; NaN in frqs/ang blanks everything."""
+    leaves that profile's TBs NaN and touches nobody else; a NaN frequency blanks everything; a NaN
+    ELEVATION blanks only its own [:, k, :] rows (the reference tests ang = [elevation_k] per k, :106)."""
     P = pr.synthetic_profiles(8, 24)
     ang = pr.BENCH_ELEVATIONS_7
     clean, _ = gpu_ctx.tb_batch("R24", P["z"], P["p"], P["t"], P["rh"], pr.HATPRO_FRQS, ang)
@@ -118,9 +119,48 @@ def test_nan_in_nan_out(gpu_ctx):
     f = pr.HATPRO_FRQS.copy(); f[3] = np.nan
     tb, valid = gpu_ctx.tb_batch("R24", P["z"], P["p"], P["t"], P["rh"], f, ang)
     assert np.isnan(tb).all() and (valid == 0).all()
-    a = ang.copy(); a[0] = np.nan
+    for bad in ([0], [3], [0, 6], [1, 2, 3, 4, 5]):
+        a = ang.copy(); a[bad] = np.nan
+        keep = ~np.isnan(a)
+        for policy in (1, 2):                                  # lane = level and lane = frequency kernels
+            gpu_ctx.set_kernel_policy(policy)
+            try:
+                tb, valid, ex = gpu_ctx.tb_batch("R24", P["z"], P["p"], P["t"], P["rh"], pr.HATPRO_FRQS, a, extras=True)
+            finally:
+                gpu_ctx.set_kernel_policy(0)
+            assert np.isnan(tb[:, bad, :]).all() and (valid == 1).all()
+            for k in ("tbatm", "tmr", "tauwet", "taudry"):
+                assert np.isnan(ex[k][:, bad, :]).all() and not np.isnan(ex[k][:, keep, :]).any()
+            assert not np.isnan(ex["taulay"]).any()            # zenith layer depths carry no angle
+            assert np.abs(tb[:, keep, :] - clean[:, keep, :]).max() < 1e-8
+    a = np.full(7, np.nan)
     tb, valid = gpu_ctx.tb_batch("R24", P["z"], P["p"], P["t"], P["rh"], pr.HATPRO_FRQS, a)
     assert np.isnan(tb).all() and (valid == 0).all()
+
+
+def test_nan_semantics_mirror_the_reference_loop(gpu_ctx):
+    """The reference's own triple loop (PyRTlib_processing.py:99-119, :153-154), restated with the
+    oracle standing in for pyrtlib, against ONE batched HIP call: slot [i, :, k, j] is NaN exactly
+    when check_for_nans(z, p, t, rh, frqs, [elev_k]) is true for that (i, j, k)."""
+    from mwr_fast_forward_operators_and_lbls_amd.pyrtlib_processing import check_for_nans
+    P = pr.synthetic_profiles(6, 61)
+    P["t"][1, 17] = np.nan
+    P["rh"][4, 0] = np.nan
+    frq = pr.HATPRO_FRQS
+    elev = pr.REFERENCE_ELEVATIONS.copy()
+    elev[[2, 9]] = np.nan
+    m = sp.get_model("R17")
+    expect = np.full((6, len(elev), len(frq)), np.nan)           # outputs pre-filled NaN (:94-97)
+    for i in range(6):
+        for k, e in enumerate(elev):
+            ang = np.array([e])
+            if check_for_nans(P["z"][i], P["p"][i], P["t"][i], P["rh"][i], frq, ang):
+                continue
+            expect[i, k] = lo.tb_cloud_rte(m, P["z"][i], P["p"][i], P["t"][i], P["rh"][i], frq, ang)["tbtotal"]
+    tb, valid = gpu_ctx.tb_batch("R17", P["z"], P["p"], P["t"], P["rh"], frq, elev)
+    assert np.array_equal(np.isnan(tb), np.isnan(expect))
+    assert np.nanmax(np.abs(tb - expect)) < TOL_K
+    assert list(valid) == [1, 0, 1, 1, 0, 1]
 
 
 def test_negative_absorption_is_flagged(gpu_ctx):
@@ -198,6 +238,35 @@ def test_device_pointer_entry(gpu_ctx):
                             d["rh"].data_ptr(), frq, ang, out.data_ptr(), val.data_ptr(), stream=st)
     torch.cuda.synchronize()
     assert np.array_equal(out.cpu().numpy(), host) and np.array_equal(val.cpu().numpy(), hv)
+
+
+def test_result_is_ordered_on_the_callers_stream(gpu_ctx):
+    """A torch user passes torch.cuda.current_stream().cuda_stream -- 0 for torch's default stream.
+    That must mean the LEGACY DEFAULT stream (MWRT_STREAM_LEGACY), not the context's own
+    non-blocking stream: the result is consumed by later work on the same torch stream with NO
+    device-wide synchronisation in between (all_gather after the launches read stale data)."""
+    import torch
+    n = 3000
+    P = pr.synthetic_profiles(n, 27)
+    ang, frq = pr.BENCH_ELEVATIONS_7, pr.HATPRO_FRQS
+    host, _ = gpu_ctx.tb_batch("R17", P["z"], P["p"], P["t"], P["rh"], frq, ang)
+    dev = torch.device("cuda:0")
+    d = {k: torch.from_numpy(P[k]).to(dev) for k in ("z", "p", "t", "rh")}
+    out = torch.empty((n, 7, 14), dtype=torch.float64, device=dev)
+    val = torch.empty(n, dtype=torch.uint8, device=dev)
+    side = torch.cuda.Stream()
+    for label, ctxmgr in (("default", torch.cuda.stream(torch.cuda.default_stream())), ("side", torch.cuda.stream(side))):
+        with ctxmgr:
+            st = torch.cuda.current_stream().cuda_stream
+            assert (st == 0) == (label == "default")
+            for rep in range(3):
+                out.zero_()                                      # same stream: ordered before the launch
+                gpu_ctx.tb_batch_device("R17", n, 180, d["z"].data_ptr(), d["p"].data_ptr(), d["t"].data_ptr(),
+                                        d["rh"].data_ptr(), frq, ang, out.data_ptr(), val.data_ptr(), stream=st)
+                got = out.clone()                                # same stream: must see the finished launch
+                got_host = got.cpu().numpy()                     # waits for THIS stream only
+                assert np.array_equal(got_host, host), (label, rep)
+    torch.cuda.synchronize()
 
 
 def test_reference_call_surface_end_to_end(gpu_ctx):

@@ -5,11 +5,17 @@ Run this where pyrtlib is installed (it is NOT in the build image, so this scrip
 executed there: treat it as a starting point and check the attribute names against your
 pyrtlib version).  It closes the "parity unpinned" gap of DESIGN.md section 2 with data, not code:
 
-    python tools/export_pyrtlib_tables.py R24 > R24_pyrtlib.json
+    python tools/export_pyrtlib_tables.py R24 [--set key=value ...] [--o2-post-scale X] > R24_pyrtlib.json
     >>> from mwr_fast_forward_operators_and_lbls_amd import spectroscopy as sp
     >>> sp.register_model(sp.ModelTables.from_json(open("R24_pyrtlib.json").read()), overwrite=True)
 
-Only the line lists and scalar switches are taken from pyrtlib; the arithmetic stays ours.
+Only the line lists and the scalars pyrtlib exposes as attributes are read from pyrtlib; the
+arithmetic stays ours.  The scalar switches pyrtlib keeps INSIDE its routines (o2_coef, o2_nonres,
+o2_wv_factor, the pvap divisors, the N2 constants ...) are filled in per model name from the
+literature and listed under "_unverified_scalars" in the output: check each against your
+pyrtlib's absorption_model.py and correct it with ``--set key=value``.  A constant factor your
+pyrtlib applies to the O2 sum and this schema has no field for (e.g. the 1.004 isotopologue factor of
+newer o2abs releases) goes in with ``--o2-post-scale``: it is folded into o2_coef.
 """
 import json
 import sys
@@ -25,7 +31,25 @@ def arr(ll, *names, n=None, scale=1.0):
     return [0.0] * n
 
 
-def main(model: str):
+def apply_overrides(out: dict, sets, o2_post_scale: float = 1.0) -> dict:
+    """``--set key=value`` overrides of scalar fields and the O2 post-scale; pure dict work (testable
+    without pyrtlib)."""
+    unverified = list(out.get("_unverified_scalars", []))
+    for item in sets:
+        key, _, val = item.partition("=")
+        if key not in out or key.startswith("_") or isinstance(out[key], (dict, list)) or out[key] is None:
+            raise SystemExit(f"--set {key}: not a scalar field of the table record")
+        out[key] = val if isinstance(out[key], str) else type(out[key])(float(val))
+        if key in unverified:
+            unverified.remove(key)
+    if o2_post_scale != 1.0:
+        out["o2_coef"] = out["o2_coef"] * o2_post_scale
+        out["provenance"] += f"; o2_coef includes a post-scale of {o2_post_scale!r}"
+    out["_unverified_scalars"] = unverified
+    return out
+
+
+def main(model: str, sets=(), o2_post_scale: float = 1.0):
     from pyrtlib.absorption_model import H2OAbsModel, O2AbsModel  # noqa: F401 (needs pyrtlib)
 
     H2OAbsModel.model = model
@@ -36,7 +60,7 @@ def main(model: str):
     nh, no = len(h.fl), len(o.f)
     old = model in ("R98", "R03", "R16", "R17")
     out = {
-        "name": model, "provenance": f"exported from pyrtlib ({model})",
+        "name": model, "provenance": f"exported from pyrtlib ({model})", "parity": "exported", "alias_of": None,
         "h2o_reftcon": float(h.reftcon), "h2o_reftline": float(h.reftline),
         "h2o_cf": float(h.cf), "h2o_xcf": float(h.xcf), "h2o_cs": float(h.cs), "h2o_xcs": float(h.xcs),
         "h2o_pvap_div": 217.0 if old else 216.68,
@@ -65,9 +89,24 @@ def main(model: str):
         "n2_n": 1.0 if model == "R98" or not old else 1.29,
         "n2_fdep": 0 if model == "R98" else 1, "n2_ptot": 1 if old else 0,
     }
+    # everything above that did not come from a pyrtlib attribute
+    out["_unverified_scalars"] = ["h2o_pvap_div", "h2o_den_coef", "h2o_shift_mode", "o2_pvap_div", "o2_wv_factor",
+                                  "o2_nonres", "o2_coef", "o2_mix_mode", "o2_line1_dens",
+                                  "n2_l", "n2_m", "n2_n", "n2_fdep", "n2_ptot"]
+    for k, attr in (("o2_x", "x"), ("o2_wb300", "wb300")):
+        if not hasattr(o, attr):
+            out["_unverified_scalars"].append(k)
+    out = apply_overrides(out, sets, o2_post_scale)
     print(json.dumps(out, indent=1))
-    print("# CHECK the scalar switches above against your pyrtlib's absorption_model.py", file=sys.stderr)
+    print("# unverified scalar switches (hard-coded per model name, NOT read from pyrtlib): "
+          + ", ".join(out["_unverified_scalars"]), file=sys.stderr)
 
 
 if __name__ == "__main__":
-    main(sys.argv[1] if len(sys.argv) > 1 else "R24")
+    import argparse
+    ap = argparse.ArgumentParser()
+    ap.add_argument("model", nargs="?", default="R24")
+    ap.add_argument("--set", action="append", default=[], metavar="KEY=VALUE")
+    ap.add_argument("--o2-post-scale", type=float, default=1.0)
+    a = ap.parse_args()
+    main(a.model, a.set, a.o2_post_scale)
