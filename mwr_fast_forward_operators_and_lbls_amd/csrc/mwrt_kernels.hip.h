@@ -160,35 +160,81 @@ constexpr double FAR_MIN_GHZ = 0.2;
 constexpr double FAR_SHIFT_GHZ = 0.05;     // O2: |dnu| allowance, checked per line by wave vote
 constexpr double FAR_H2O_GHZ = 5.0;        // H2O: covers any pressure shift (< 1 GHz) with margin
 
-// one bit per line, identical in every wave: lane k tests line k against the nfc chunk frequencies
-__device__ __forceinline__ unsigned long long far_line_mask(const double* sfq, int nslots, int nlines,
-                                                            const __attribute__((address_space(4))) double* centre,
-                                                            double margin, int lane) {
-  bool far = false;
-  if (lane < nlines) {
-    const double c = centre[lane];
+// Wave-uniform bit sets over line indices, identical in every wave of the workgroup: lane k tests
+// line k of the table against the chunk's frequencies, one ballot per set.  They steer the line
+// loops: each loop walks ONE set with ONE loop body, so the NFC accumulators never cross a
+// control-flow join between differently allocated variants (the v_mov copies that cost).
+struct LineMasks {
+  unsigned long long o2_far;   // every chunk frequency >= FAR_MIN_GHZ + FAR_SHIFT_GHZ from the line centre
+  unsigned h2o_far;            // ... >= FAR_H2O_GHZ from the line centre
+  unsigned h2o_none;           // both Lorentz terms beyond the 750-GHz cutoff for every frequency (FAR_H2O_GHZ margin)
+  unsigned h2o_sd;             // speed-dependent lines (W2 > 0)
+};
+
+template <class ModelPtr>
+__device__ __forceinline__ LineMasks line_masks(ModelPtr M, const double* sfq, int nslots, int lane) {
+  bool far_o = false, far_h = false, none_h = false, sd_h = false;
+  const int n_o2 = M->n_o2, n_h2o = M->n_h2o;
+  if (lane < n_o2) {
+    const double c = M->o2_f[lane];
     double dmin = 1e300;
     for (int j = 0; j < nslots; ++j) dmin = fmin(dmin, fabs(sfq[2 * j] - c));
-    far = dmin >= margin;
+    far_o = dmin >= FAR_MIN_GHZ + FAR_SHIFT_GHZ;
   }
-  return __ballot(far);
+  if (lane < n_h2o) {
+    const double c = M->h2o_fl[lane];
+    double dmin = 1e300, smin = 1e300;
+    for (int j = 0; j < nslots; ++j) { const double f = sfq[2 * j]; dmin = fmin(dmin, fabs(f - c)); smin = fmin(smin, fabs(f + c)); }
+    far_h = dmin >= FAR_H2O_GHZ;
+    none_h = dmin >= 750.0 + FAR_H2O_GHZ && smin >= 750.0 + FAR_H2O_GHZ;
+    sd_h = M->h2o_w2[lane] > 0.0;
+  }
+  LineMasks lm;
+  lm.o2_far = __ballot(far_o);
+  lm.h2o_far = (unsigned)__ballot(far_h);
+  lm.h2o_none = (unsigned)__ballot(none_h);
+  lm.h2o_sd = (unsigned)__ballot(sd_h);
+  return lm;
 }
 
 struct cplx { double re, im; };
 __device__ __forceinline__ cplx cmul(cplx a, cplx b) { return {a.re * b.re - a.im * b.im, a.re * b.im + a.im * b.re}; }
 __device__ __forceinline__ cplx cadd(cplx a, double r) { return {a.re + r, a.im}; }
-__device__ __forceinline__ cplx cdiv(cplx a, cplx b) {
-  double d = b.re * b.re + b.im * b.im;
-  return {fdiv(a.re * b.re + a.im * b.im, d), fdiv(a.im * b.re - a.re * b.im, d)};
+// 1 / b for complex b (one real reciprocal): the speed-dependent shape divides twice by the same
+// per-(level, line) quantity, so the loop body multiplies by this instead
+__device__ __forceinline__ cplx crecip(cplx b) {
+  const double d = __builtin_fma(b.re, b.re, b.im * b.im);
+#if MWRT_EXACT_DIV
+  const double r = 1.0 / d;
+#else
+  double r = __builtin_amdgcn_rcp(d);
+  r = __builtin_fma(r, __builtin_fma(-d, r, 1.0), r);
+  r = __builtin_fma(r, __builtin_fma(-d, r, 1.0), r);
+#endif
+  return {b.re * r, -b.im * r};
+}
+__device__ __forceinline__ cplx cdiv(cplx a, cplx b) { return cmul(a, crecip(b)); }
+// sqrt(x), x >= 0 finite and far from the denormal range: v_rsq_f64 seed (~2^-23) + one coupled
+// Newton step on (g ~ sqrt x, h ~ 1/(2 sqrt x)) -> ~2^-45 relative
+__device__ __forceinline__ double fsqrt(double x) {
+#if MWRT_EXACT_DIV
+  return sqrt(x);
+#else
+  const double y = __builtin_amdgcn_rsq(x);
+  double g = x * y;
+  const double h = 0.5 * y;
+  g = __builtin_fma(__builtin_fma(-g, g, x), h, g);
+  return (x > 0.0) ? g : 0.0;
+#endif
 }
 __device__ __forceinline__ cplx csqrt_principal(cplx z) {
-  double r = sqrt(z.re * z.re + z.im * z.im);
-  if (z.re >= 0.0) {
-    double a = sqrt(0.5 * (r + z.re));
-    return {a, (a > 0.0) ? fdiv(z.im, 2.0 * a) : 0.0};
-  }
-  double b = sqrt(0.5 * (r - z.re));
-  return {fdiv(fabs(z.im), 2.0 * b), copysign(b, z.im)};
+  const double r = fsqrt(__builtin_fma(z.re, z.re, z.im * z.im));
+  // one square root and one division, selected by the sign of Re z:
+  //   Re z >= 0: a = sqrt((r + Re z)/2), result (a, Im z / 2a);  Re z < 0: b = sqrt((r - Re z)/2), result (|Im z| / 2b, +-b)
+  const bool pos = z.re >= 0.0;
+  const double a = fsqrt(0.5 * (r + fabs(z.re)));
+  const double q = (a > 0.0) ? fdiv1(pos ? z.im : fabs(z.im), a + a) : 0.0;
+  return pos ? cplx{a, q} : cplx{q, copysign(a, z.im)};
 }
 
 // Rosenkranz DCERROR [EXT]: Hui, Armstrong & Wray (1978) rational approximation of the complex
@@ -299,9 +345,52 @@ __device__ __forceinline__ H2OLine h2o_line(cmodel M, int k, double pda, double 
   return q;
 }
 
+// Far-line bodies shared by the H2O and O2 loops: the two Lorentz terms of a line whose centre is
+// far from every frequency of the chunk collapse to one rational function of f^2,
+//   (f^2 P + Q) / (f^4 + A2 f^2 + Bc),   A2 = 2 (w^2 - c^2),  Bc = (c^2 + w^2)^2
+// (cancellation in the denominator <= f^2 / (4 FAR_MIN^2) ulp ~ 2e-12).
+struct FarLine { double P, Q, A2, Bc; };
+
+// FOUR far lines per frequency through ONE reciprocal:
+//   n0/d0 + n1/d1 + n2/d2 + n3/d3 = ((n0 d1 + n1 d0) d2 d3 + (n2 d3 + n3 d2) d0 d1) / (d0 d1 d2 d3).
+// v_rcp_f64 costs about three FMA issue slots and delivers 2^-23, so a reciprocal + Newton step is 5 of
+// the 9 slots a line-frequency term costs on its own; shared by four lines the term costs 6.6.
+// 24 FMA-class instructions + 1 rcp per frequency (products stay < 1e48 for centres <= 1 THz).
+template <int NFC>
+__device__ __forceinline__ void far_quad_accumulate(const double* sfq, const FarLine& a, const FarLine& b,
+                                                    const FarLine& c, const FarLine& d, double (&sum)[NFC]) {
+#pragma unroll
+  for (int j = 0; j < NFC; ++j) {
+    const double f2 = sfq[2 * j + 1];
+    const double d0 = __builtin_fma(f2, f2 + a.A2, a.Bc);
+    const double d1 = __builtin_fma(f2, f2 + b.A2, b.Bc);
+    const double d2 = __builtin_fma(f2, f2 + c.A2, c.Bc);
+    const double d3 = __builtin_fma(f2, f2 + d.A2, d.Bc);
+    const double n0 = __builtin_fma(f2, a.P, a.Q);
+    const double n1 = __builtin_fma(f2, b.P, b.Q);
+    const double n2 = __builtin_fma(f2, c.P, c.Q);
+    const double n3 = __builtin_fma(f2, d.P, d.Q);
+    const double p01 = d0 * d1, p23 = d2 * d3;
+    const double m01 = __builtin_fma(n0, d1, n1 * d0);
+    const double m23 = __builtin_fma(n2, d3, n3 * d2);
+    const double den = p01 * p23;
+    const double num = __builtin_fma(m01, p23, m23 * p01);
+    double r = __builtin_amdgcn_rcp(den);
+    r = __builtin_fma(r, __builtin_fma(-den, r, 1.0), r);
+    sum[j] = __builtin_fma(num, r, sum[j]);
+  }
+}
+
+// lowest `n` set bits of `m` (n < 4): the lines a quad loop leaves to the general loop
+__device__ __forceinline__ unsigned long long lowest_bits(unsigned long long m, int n) {
+  unsigned long long out = 0;
+  for (int i = 0; i < n; ++i) { const unsigned long long b = m & (0ull - m); out |= b; m ^= b; }
+  return out;
+}
+
 template <int NFC>
 __device__ __forceinline__ void h2o_absorb(cmodel M, const LevelState& L, const double* sfq /*LDS: {f, f^2} per slot*/,
-                                           unsigned far_h2o, double (&awet)[NFC]) {
+                                           const LineMasks& lm, double (&awet)[NFC]) {
   const double t = L.t;
   const double pvap = fdiv(L.rho * t, M->h2o_pvap_div);
   const double pda = L.p - pvap;
@@ -317,43 +406,56 @@ __device__ __forceinline__ void h2o_absorb(cmodel M, const LevelState& L, const 
   for (int j = 0; j < NFC; ++j) sum[j] = 0.0;
 
   const int nl = M->n_h2o;
-  int n_sd = 0;
+  const unsigned all = (nl >= 32) ? 0xffffffffu : ((1u << nl) - 1u);
   // The 750-GHz cutoff of each Lorentz term depends on the lane only through the (tiny) pressure
-  // shift.  Per line the wave votes once whether every lane agrees for EVERY frequency of the
-  // chunk (tested at the chunk's extreme frequencies); if so the masks drop out of the hot loop:
-  //   both terms in   : s w (D1 + D2)/(D1 D2) - 2 s base     (the usual case)
-  //   resonant only   : s w / D1 - s base                     (e.g. 752 GHz seen from 22 GHz)
-  //   none            : line skipped                          (e.g. 916 GHz)
-  // anything else (and the speed-dependent lines) takes the masked form.
+  // shift.  Three loops, each with ONE body:
+  //   A  far lines (table centre >= FAR_H2O_GHZ from every frequency), both terms inside the cutoff for
+  //      every lane (wave vote at the chunk's extreme frequencies): the rational form, no masks.
+  //      A line that fails the vote is handed to loop B.
+  //   B  everything else that is not speed dependent: resonant-only / near-centre / masked forms.
+  //   C  speed-dependent lines (22 / 183 GHz in R20SD+): Lorentz pair + the SD resonant shape.
+  // Lines whose two terms are beyond the cutoff for every frequency (e.g. 916 GHz from 22 GHz) are skipped.
   const double fmin = sfq[2 * NFC], fmax = sfq[2 * NFC + 1];
   double bsum = 0.0;                                          // sum of (count * s * base), frequency independent
-  for (int k = 0; k < ((MWRT_ABLATE & 2) ? 0 : nl); ++k) {
+  unsigned deferred = ~lm.h2o_far & ~lm.h2o_sd & ~lm.h2o_none & all;
+  const unsigned setA = (MWRT_ABLATE & 2) ? 0u : (lm.h2o_far & ~lm.h2o_sd & ~lm.h2o_none & all);
+  // loop A walks its lines FOUR at a time (far_quad_accumulate); the count mod 4 left over joins loop B
+  const unsigned leftA = (unsigned)lowest_bits(setA, __builtin_popcount(setA) & 3);
+  deferred |= leftA;
+  auto far_setup = [&](int k, FarLine& fl) {
     const H2OLine q = h2o_line(M, k, pda, pvap, ti, tiln, ti2, shifted);
-    const bool sd_line = M->h2o_w2[k] > 0.0;                  // wave-uniform
-    n_sd += sd_line ? 1 : 0;
+    const bool d1_in = (q.c1 - fmin < 750.0) && (fmax - q.c1 < 750.0) && (q.c1 - fmin > -750.0);
+    const bool d2_in = fmax + q.c1 < 750.0 && fmin + q.c1 > -750.0;
+    // both terms in:  s w (D1 + D2)/(D1 D2) - 2 s base,  D1 + D2 = 2 f^2 + 2 (c^2 + w^2)
+    const double cc = __builtin_fma(q.c1, q.c1, q.wsq);
+    fl.A2 = 2.0 * __builtin_fma(-q.c1, q.c1, q.wsq);
+    fl.Bc = cc * cc;
+    double P = 2.0 * q.sw, bs = 2.0 * q.sbase;
+    if (!__all(d1_in && d2_in)) { deferred |= 1u << k; P = 0.0; bs = 0.0; }     // cutoff not uniform: loop B's job
+    fl.P = P;
+    fl.Q = P * cc;
+    bsum += bs;
+  };
+  for (unsigned m = setA & ~leftA; m;) {
+    FarLine q0, q1, q2, q3;
+    far_setup(__builtin_ctz(m), q0); m &= m - 1u;
+    far_setup(__builtin_ctz(m), q1); m &= m - 1u;
+    far_setup(__builtin_ctz(m), q2); m &= m - 1u;
+    far_setup(__builtin_ctz(m), q3); m &= m - 1u;
+    LDS_RELOAD_FENCE();
+    far_quad_accumulate<NFC>(sfq, q0, q1, q2, q3, sum);
+  }
+  if (MWRT_ABLATE & 2) deferred = 0u;
+  for (unsigned m = deferred; m; m &= m - 1u) {
+    const int k = __builtin_ctz(m);
+    const H2OLine q = h2o_line(M, k, pda, pvap, ti, tiln, ti2, shifted);
     const bool d1_in = (q.c1 - fmin < 750.0) && (fmax - q.c1 < 750.0) && (q.c1 - fmin > -750.0);
     const bool d1_out = (q.c1 - fmax >= 750.0) || (fmin - q.c1 >= 750.0);
     const bool d2_in = fmax + q.c1 < 750.0 && fmin + q.c1 > -750.0;
     const bool d2_out = fmin + q.c1 >= 750.0;
-    const bool all_both = !sd_line && __all(d1_in && d2_in);
-    const bool all_res = !sd_line && __all(d1_in && d2_out);
-    const bool all_none = !sd_line && __all(d1_out && d2_out);
+    if (__all(d1_out && d2_out)) continue;
     LDS_RELOAD_FENCE();
-    if (all_both && ((far_h2o >> k) & 1u)) {
-      bsum = __builtin_fma(2.0, q.sbase, bsum);
-      const double cc = __builtin_fma(q.c1, q.c1, q.wsq);
-      const double A2 = 2.0 * __builtin_fma(-q.c1, q.c1, q.wsq);
-      const double Bc = cc * cc;
-      const double C2 = 2.0 * cc;
-#pragma unroll
-      for (int j = 0; j < NFC; ++j) {
-        const double f2 = sfq[2 * j + 1];
-        const double den12 = __builtin_fma(f2, f2 + A2, Bc);          // D1 D2
-        double r = __builtin_amdgcn_rcp(den12);
-        r = __builtin_fma(r, __builtin_fma(-den12, r, 1.0), r);
-        sum[j] = __builtin_fma(__builtin_fma(2.0, f2, C2) * r, q.sw, sum[j]);   // D1 + D2 = 2 f^2 + 2 (c^2 + w^2)
-      }
-    } else if (all_both) {
+    if (__all(d1_in && d2_in)) {                               // next to a line centre: detunings formed directly
       bsum = __builtin_fma(2.0, q.sbase, bsum);
 #pragma unroll
       for (int j = 0; j < NFC; ++j) {
@@ -367,7 +469,7 @@ __device__ __forceinline__ void h2o_absorb(cmodel M, const LevelState& L, const 
         r = __builtin_fma(r, __builtin_fma(-den12, r, 1.0), r);
         sum[j] = __builtin_fma((D1 + D2) * r, q.sw, sum[j]);
       }
-    } else if (all_res) {
+    } else if (__all(d1_in && d2_out)) {                       // resonant term only (e.g. 752 GHz seen from 22 GHz)
       bsum += q.sbase;
 #pragma unroll
       for (int j = 0; j < NFC; ++j) {
@@ -377,8 +479,7 @@ __device__ __forceinline__ void h2o_absorb(cmodel M, const LevelState& L, const 
         r = __builtin_fma(r, __builtin_fma(-D1, r, 1.0), r);
         sum[j] = __builtin_fma(r, q.sw, sum[j]);
       }
-    } else if (!all_none) {
-      const double sdlim = sd_line ? 10.0 * q.w0 : -1.0;      // |d1| < sdlim -> handled by the SD loop
+    } else {                                                    // cutoff differs between lanes / frequencies: masks
 #pragma unroll
       for (int j = 0; j < NFC; ++j) {
         const double f = sfq[2 * j];
@@ -386,8 +487,7 @@ __device__ __forceinline__ void h2o_absorb(cmodel M, const LevelState& L, const 
         const double d2 = f + q.c1;
         const double D1 = __builtin_fma(d1, d1, q.wsq);
         const double D2 = __builtin_fma(d2, d2, q.wsq);
-        const double a1 = fabs(d1);
-        const double m1 = (a1 < 750.0 && !(a1 < sdlim)) ? 1.0 : 0.0;
+        const double m1 = (fabs(d1) < 750.0) ? 1.0 : 0.0;
         const double m2 = (fabs(d2) < 750.0) ? 1.0 : 0.0;
         const double num = __builtin_fma(m2, D1, m1 * D2);
         const double r = fdiv1(num, D1 * D2);
@@ -398,32 +498,51 @@ __device__ __forceinline__ void h2o_absorb(cmodel M, const LevelState& L, const 
   }
 #pragma unroll
   for (int j = 0; j < NFC; ++j) sum[j] -= bsum;
-  if (n_sd > 0 && !(MWRT_ABLATE & 4)) {
-    // speed-dependent resonant shape factor (ABH2O_SD) for the lines that carry W2 > 0:
-    //   Xc = (w0 - 1.5 w2 + i (d1 + 1.5 delta2)) / (w2 - i delta2);  SD = 2 (1 - sqrt(pi) Xrt w(i Xrt)) / (w2 - i delta2)
-    for (int k = 0; k < nl; ++k) {
-      if (!(M->h2o_w2[k] > 0.0)) continue;
-      const H2OLine q = h2o_line(M, k, pda, pvap, ti, tiln, ti2, shifted);
-      const double w2 = M->h2o_w2[k] * pda * fexp(M->h2o_xw2[k] * tiln) + M->h2o_w2s[k] * pvap * fexp(M->h2o_xw2s[k] * tiln);
-      const double delta2 = M->h2o_d2[k] * pda + M->h2o_d2s[k] * pvap;
-      const cplx den2 = {w2, -delta2};
+  // speed-dependent lines (ABH2O_SD): the resonant term inside |d1| < 10 w0 is the quadratic-speed-dependent
+  // shape      Xc = (w0 - 1.5 w2 + i (d1 + 1.5 delta2)) / (w2 - i delta2),
+  //            SD = 2 (1 - sqrt(pi) Xrt w(i Xrt)) / (w2 - i delta2),   Xrt = sqrt(Xc)
+  // instead of the Lorentzian; outside it, and for the second term, the plain cutoff Lorentzians.
+  const unsigned setC = (MWRT_ABLATE & 4) ? 0u : (lm.h2o_sd & all);
+  for (unsigned m = setC; m; m &= m - 1u) {
+    const int k = __builtin_ctz(m);
+    const H2OLine q = h2o_line(M, k, pda, pvap, ti, tiln, ti2, shifted);
+    const double w2 = M->h2o_w2[k] * pda * fexp(M->h2o_xw2[k] * tiln) + M->h2o_w2s[k] * pvap * fexp(M->h2o_xw2s[k] * tiln);
+    const double delta2 = M->h2o_d2[k] * pda + M->h2o_d2s[k] * pvap;
+    const cplx iden2 = crecip(cplx{w2, -delta2});              // 1 / (w2 - i delta2), once per (level, line)
+    const double sdlim = (w2 > 0.0) ? 10.0 * q.w0 : -1.0;     // width2 == 0 at this level: plain Lorentz
+    const double xre = q.w0 - 1.5 * w2, xim0 = 1.5 * delta2;
+    LDS_RELOAD_FENCE();
+    // pass 1: the cutoff Lorentzians, the resonant one masked out where the SD shape takes over
 #pragma unroll
-      for (int j = 0; j < NFC; ++j) {
-        const double d1 = sfq[2 * j] - q.c1;
-        if (fabs(d1) < 10.0 * q.w0) {
-          double r1;
-          if (w2 > 0.0) {
-            cplx xc = cdiv(cplx{q.w0 - 1.5 * w2, d1 + 1.5 * delta2}, den2);
-            cplx xrt = csqrt_principal(xc);
-            cplx w = dcerror_upper(-xrt.im, xrt.re);
-            cplx pxw = cmul(cplx{1.77245385090551603 * xrt.re, 1.77245385090551603 * xrt.im}, w);
-            cplx sd = cdiv(cplx{2.0 * (1.0 - pxw.re), -2.0 * pxw.im}, den2);
-            r1 = sd.re - q.base;
-          } else {                                              // width2 == 0: plain Lorentz + cutoff
-            r1 = (fabs(d1) < 750.0) ? (fdiv(q.w0, __builtin_fma(d1, d1, q.wsq)) - q.base) : 0.0;
-          }
-          sum[j] = __builtin_fma(q.s, r1, sum[j]);
-        }
+    for (int j = 0; j < NFC; ++j) {
+      const double f = sfq[2 * j];
+      const double d1 = f - q.c1;
+      const double d2 = f + q.c1;
+      const double D1 = __builtin_fma(d1, d1, q.wsq);
+      const double D2 = __builtin_fma(d2, d2, q.wsq);
+      const double a1 = fabs(d1);
+      const double m1 = (a1 < 750.0 && !(a1 < sdlim)) ? 1.0 : 0.0;
+      const double m2 = (fabs(d2) < 750.0) ? 1.0 : 0.0;
+      const double num = __builtin_fma(m2, D1, m1 * D2);
+      const double r = fdiv1(num, D1 * D2);
+      sum[j] = __builtin_fma(r, q.sw, sum[j]);
+      sum[j] = __builtin_fma(-(m1 + m2), q.sbase, sum[j]);
+    }
+    // pass 2: the SD resonant shape, frequency by frequency, only where some lane of the wave is inside
+    // 10 half-widths (the branch is wave-uniform, so nothing of one frequency interleaves with the next)
+    LDS_RELOAD_FENCE();
+#pragma unroll
+    for (int j = 0; j < NFC; ++j) {
+      const double d1 = sfq[2 * j] - q.c1;
+      const bool inner = fabs(d1) < sdlim;
+      if (__any(inner)) {
+        const cplx xc = cmul(cplx{xre, d1 + xim0}, iden2);
+        const cplx xrt = csqrt_principal(xc);
+        const cplx w = dcerror_upper(-xrt.im, xrt.re);
+        const cplx pxw = cmul(cplx{1.77245385090551603 * xrt.re, 1.77245385090551603 * xrt.im}, w);
+        const cplx sd = cmul(cplx{2.0 * (1.0 - pxw.re), -2.0 * pxw.im}, iden2);
+        const double r1 = inner ? sd.re - q.base : 0.0;
+        sum[j] = __builtin_fma(q.s, r1, sum[j]);
       }
     }
   }
@@ -439,9 +558,16 @@ __device__ __forceinline__ void h2o_absorb(cmodel M, const LevelState& L, const 
 // K1b: O2 lines + non-resonant + N2 continuum (O2AbsModel.o2_absorption / N2AbsModel [EXT])
 //   S (f/F)^2 [ (w g + d1 Y)/D1 + (w g - d2 Y)/D2 ]  with one reciprocal per line and frequency
 // ---------------------------------------------------------------------------------------------
+struct O2Line {            // per-(level, line) quantities, frequency independent (all carry HALF the line's weight:
+  double c1, df2;          //  the common factor 2 of P and Q is applied once, in the final scale)
+  double P, Q;             //  n1/D1 + n2/D2 = 2 (f^2 P + Q) / (D1 D2),  P = a + c b,  Q = (c^2 + w^2)(a - c b)
+  double cc;               //  c^2 + w^2
+  double dnu;
+};
+
 template <int NFC>
 __device__ __forceinline__ void dry_absorb(cmodel M, const LevelState& L, const double* sfq /*LDS: {f, f^2} per slot*/,
-                                           unsigned long long far_o2, double (&adry)[NFC]) {
+                                           const LineMasks& lm, double (&adry)[NFC]) {
   const double temp = L.t;
   const double pres = L.p;
   const double th = fdiv(300.0, temp);
@@ -456,6 +582,7 @@ __device__ __forceinline__ void dry_absorb(cmodel M, const LevelState& L, const 
   const double pe2 = den * den;
   const bool second = M->o2_mix_mode != 0;
   const double ymul = second ? den : 0.001 * pres * b;
+  const bool line1_dens = !second && M->o2_line1_dens;
 
   double sum[NFC];
 #pragma unroll
@@ -464,69 +591,91 @@ __device__ __forceinline__ void dry_absorb(cmodel M, const LevelState& L, const 
   // With d1 = f - c, d2 = f + c, D = d^2 + w^2, n1 = a + d1 b, n2 = a - d2 b the two terms of a line
   // share one reciprocal and the numerator collapses to a polynomial in f^2:
   //   n1/D1 + n2/D2 = (f^2 P + Q) / (D1 D2),  P = 2 (a + c b),  Q = 2 (c^2 + w^2)(a - c b)
-  // (D1, D2 are still formed from d1, d2 directly: no cancellation next to a line centre).
-  const int nl = (MWRT_ABLATE & 1) ? 0 : M->n_o2;
-  double be_prev = -1.0, ebe = 1.0;
-
-  for (int k = 0; k < nl; ++k) {
+  long long be_prev = -1;
+  double ebe = 1.0;
+  auto line_setup = [&](int k) -> O2Line {
     const auto& R = M->o2r[k];
-    const double fk = R.f;
-    const double y = ymul * (R.y0 + R.y1 * th1);
+    const double y = ymul * __builtin_fma(R.y1, th1, R.y0);
     double dnu = 0.0, gfac = 1.0;
     if (second) {
-      dnu = pe2 * (R.dnu0 + R.dnu1 * th1);
-      gfac = 1.0 + pe2 * (R.g0 + R.g1 * th1);
+      dnu = pe2 * __builtin_fma(R.dnu1, th1, R.dnu0);
+      gfac = __builtin_fma(pe2, __builtin_fma(R.g1, th1, R.g0), 1.0);
     }
-    const double df = R.w300 * ((k == 0 && !second && M->o2_line1_dens) ? dens : den);
-    const double be = R.be;
-    if (be != be_prev) { ebe = fexp(-be * th1); be_prev = be; }     // N- / N+ partners share BE (uniform branch)
+    const double df = R.w300 * ((k == 0 && line1_dens) ? dens : den);
+    // N- / N+ partners share BE: the exponential is redone only when the table value changes
+    // (compared as bit patterns so the test stays on the scalar unit)
+    const long long be_bits = __builtin_bit_cast(long long, R.be);
+    if (be_bits != be_prev) { ebe = fexp(-R.be * th1); be_prev = be_bits; }
     const double str = R.s300rf2 * ebe;                               // S300 / F^2 (the f^2 is applied at the end)
-    const double c1 = fk + dnu;
-    const double df2 = df * df;
-    const double a = str * df * gfac;
-    const double cb = c1 * (str * y);
-    const double P = 2.0 * (a + cb);
-    const double Q = 2.0 * __builtin_fma(c1, c1, df2) * (a - cb);
+    O2Line q;
+    q.dnu = dnu;
+    q.c1 = R.f + dnu;
+    q.df2 = df * df;
+    const double a = (str * df) * gfac;
+    const double cb = q.c1 * (str * y);
+    q.cc = __builtin_fma(q.c1, q.c1, q.df2);
+    q.P = a + cb;
+    q.Q = q.cc * (a - cb);
+    return q;
+  };
+
+  const int nl = M->n_o2;
+  const unsigned long long all = (nl >= 64) ? ~0ull : ((1ull << nl) - 1ull);
+  // loop A: far lines -- polynomial denominator; a line whose shift |dnu| exceeds the allowance at any
+  // level of this wave is handed to loop B
+  unsigned long long near = ~lm.o2_far & all;
+  const unsigned long long setA = (MWRT_ABLATE & 1) ? 0ull : (lm.o2_far & all);
+  // ... four lines at a time (far_quad_accumulate); the count mod 4 left over joins loop B
+  const unsigned long long leftA = lowest_bits(setA, __builtin_popcountll(setA) & 3);
+  near |= leftA;
+  auto far_setup = [&](int k, FarLine& fl) {
+    const O2Line q = line_setup(k);
+    double P = q.P, Q = q.Q;
+    if (second && !__all(fabs(q.dnu) < FAR_SHIFT_GHZ)) { near |= 1ull << k; P = 0.0; Q = 0.0; }
+    fl.P = P; fl.Q = Q;
+    fl.A2 = 2.0 * __builtin_fma(-q.c1, q.c1, q.df2);
+    fl.Bc = q.cc * q.cc;
+  };
+  for (unsigned long long m = setA & ~leftA; m;) {
+    FarLine q0, q1, q2, q3;
+    far_setup(__builtin_ctzll(m), q0); m &= m - 1ull;
+    far_setup(__builtin_ctzll(m), q1); m &= m - 1ull;
+    far_setup(__builtin_ctzll(m), q2); m &= m - 1ull;
+    far_setup(__builtin_ctzll(m), q3); m &= m - 1ull;
     LDS_RELOAD_FENCE();
-    if (((far_o2 >> k) & 1ull) && __all(fabs(dnu) < FAR_SHIFT_GHZ)) {
-      // every frequency of the chunk is >= FAR_MIN_GHZ from this line for every lane:
-      //   D1 D2 = f^4 + 2 (w^2 - c^2) f^2 + (c^2 + w^2)^2   (cancellation <= f^2 / (4 FAR_MIN^2) ulp ~ 2e-12)
-      const double cc = __builtin_fma(c1, c1, df2);
-      const double A2 = 2.0 * __builtin_fma(-c1, c1, df2);
-      const double Bc = cc * cc;
+    far_quad_accumulate<NFC>(sfq, q0, q1, q2, q3, sum);
+  }
+  // loop B: lines next to a chunk frequency -- D1, D2 formed from the detunings directly (no cancellation)
+  if (MWRT_ABLATE & 1) near = 0ull;
+  be_prev = -1;
+  for (unsigned long long m = near; m; m &= m - 1ull) {
+    const int k = __builtin_ctzll(m);
+    const O2Line q = line_setup(k);
+    LDS_RELOAD_FENCE();
 #pragma unroll
-      for (int j = 0; j < NFC; ++j) {
-        const double f2 = sfq[2 * j + 1];
-        const double den12 = __builtin_fma(f2, f2 + A2, Bc);
-        double r = __builtin_amdgcn_rcp(den12);
-        r = __builtin_fma(r, __builtin_fma(-den12, r, 1.0), r);
-        sum[j] = __builtin_fma(__builtin_fma(f2, P, Q), r, sum[j]);
-      }
-    } else {
-#pragma unroll
-      for (int j = 0; j < NFC; ++j) {
-        const double f = sfq[2 * j], f2 = sfq[2 * j + 1];
-        const double d1 = f - c1;
-        const double d2 = f + c1;
-        const double D1 = __builtin_fma(d1, d1, df2);
-        const double D2 = __builtin_fma(d2, d2, df2);
-        const double den12 = D1 * D2;
-        double r = __builtin_amdgcn_rcp(den12);
-        r = __builtin_fma(r, __builtin_fma(-den12, r, 1.0), r);
-        sum[j] = __builtin_fma(__builtin_fma(f2, P, Q), r, sum[j]);
-      }
+    for (int j = 0; j < NFC; ++j) {
+      const double f = sfq[2 * j], f2 = sfq[2 * j + 1];
+      const double d1 = f - q.c1;
+      const double d2 = f + q.c1;
+      const double D1 = __builtin_fma(d1, d1, q.df2);
+      const double D2 = __builtin_fma(d2, d2, q.df2);
+      const double den12 = D1 * D2;
+      double r = __builtin_amdgcn_rcp(den12);
+      r = __builtin_fma(r, __builtin_fma(-den12, r, 1.0), r);
+      sum[j] = __builtin_fma(__builtin_fma(f2, q.P, q.Q), r, sum[j]);
     }
   }
-  const double scale = M->o2_coef * presda * th * th * th;
+  const double scale2 = 2.0 * M->o2_coef * presda * th * th * th;     // the 2 of P and Q
   // N2 collision-induced continuum (ABSN2): p^2 f^2 th^m
   const double pn2 = M->n2_ptot ? pres : L.pdry;
   const double n2c = M->n2_n * M->n2_l * pn2 * pn2 * fexp(M->n2_m * lnth);
+  const double nr0 = 0.5 * M->o2_nonres * dfnr;
+  const double dfnr2 = dfnr * dfnr;
 #pragma unroll
   for (int j = 0; j < NFC; ++j) {
-    const double f = sfq[2 * j];
     const double f2 = sfq[2 * j + 1];
-    const double nonres = fdiv(M->o2_nonres * f2 * dfnr, th * (f2 + dfnr * dfnr));
-    double o2 = scale * __builtin_fma(sum[j], f2, nonres);
+    const double hnonres = fdiv(nr0 * f2, th * (f2 + dfnr2));          // half the non-resonant term
+    double o2 = scale2 * __builtin_fma(sum[j], f2, hnonres);
     o2 = fmax(o2, 0.0);
     adry[j] = o2 + n2c * sfq[2 * NFC + 2 + j] * f2;          // N2 frequency-dependence factor, per slot
   }
@@ -534,11 +683,46 @@ __device__ __forceinline__ void dry_absorb(cmodel M, const LevelState& L, const 
 
 // RTEquation.exponential_integration [EXT]: log-mean ("exponential decay") layer value.
 // Branch order is the contract.  Returns NaN-flag through `neg`.
+//
+// The log-mean itself: with s = (x1 - x0)/(x1 + x0),  ln(x1/x0) = 2 atanh(s), so
+//   (x1 - x0)/ln(x1/x0) = (x1 + x0)/2 / (1 + s^2/3 + s^4/5 + ...).
+// Adjacent levels of a sounding differ by a few percent, so |s| <= LOGMEAN_SMALL_S for a whole wave is
+// the usual case (wave vote): one division and a 10-term series instead of a division, a full log
+// (frexp, second division, series) and a third division.  It is also better conditioned than the
+// quotient form, which loses up to 1e-7 relative when x1 - x0 is just above the 1e-9 switch.
+constexpr double LOGMEAN_SMALL_S = 0.1715;      // |s| <= this: series truncation s^22/23 < 7e-19
 __device__ __forceinline__ double layer_value(double x1, double x0, bool& neg) {
-  if (x0 < 0.0 || x1 < 0.0) { neg = true; return 0.0; }
-  if (fabs(x1 - x0) < 1e-09) return x1;
-  if (x0 == 0.0 || x1 == 0.0) return (x1 + x0) * 0.5;          // zeroflg = True for wet & dry
-  return fdiv1(x1 - x0, flog(fdiv(x1, x0)));
+  const double d = x1 - x0;
+  const double sm = x1 + x0;
+  const bool negative = x0 < 0.0 || x1 < 0.0;
+  const bool same = fabs(d) < 1e-09;
+  const bool zero = x0 == 0.0 || x1 == 0.0;
+  const bool special = negative || same || zero;
+  double r;
+  const double s = fdiv1(d, sm);
+  if (__all(special || fabs(s) <= LOGMEAN_SMALL_S)) {
+    const double z = s * s;
+    double p = 4.3478260869565216e-02;                    // 1/23
+    MWRT_FMA_SC(p, z, 4.7619047619047616e-02);            // 1/21
+    MWRT_FMA_SC(p, z, 5.2631578947368418e-02);            // 1/19
+    MWRT_FMA_SC(p, z, 5.8823529411764705e-02);            // 1/17
+    MWRT_FMA_SC(p, z, 6.6666666666666666e-02);            // 1/15
+    MWRT_FMA_SC(p, z, 7.6923076923076927e-02);            // 1/13
+    MWRT_FMA_SC(p, z, 9.0909090909090912e-02);            // 1/11
+    MWRT_FMA_SC(p, z, 1.1111111111111110e-01);            // 1/9
+    MWRT_FMA_SC(p, z, 1.4285714285714285e-01);            // 1/7
+    MWRT_FMA_SC(p, z, 2.0000000000000001e-01);            // 1/5
+    MWRT_FMA_SC(p, z, 3.3333333333333331e-01);            // 1/3
+    p = __builtin_fma(p, z, 1.0);
+    r = fdiv1(0.5 * sm, p);
+  } else {
+    r = fdiv1(d, flog(fdiv(x1, x0)));
+  }
+  if (negative) neg = true;
+  r = zero ? sm * 0.5 : r;                                      // zeroflg = True for wet & dry
+  r = same ? x1 : r;
+  r = negative ? 0.0 : r;
+  return r;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -647,10 +831,9 @@ k_tb_fused(const FusedArgs A) {
   {
     const double e = goff_gratch_e(ti, rhi);
     const LevelState L = level_state(pi, ti, e);
-    const unsigned long long far_o2 = far_line_mask(sfq, NFC, M->n_o2, M->o2_f, FAR_MIN_GHZ + FAR_SHIFT_GHZ, lane);
-    const unsigned far_h2o = (unsigned)far_line_mask(sfq, NFC, M->n_h2o, M->h2o_fl, FAR_H2O_GHZ, lane);
-    h2o_absorb<NFC>(M, L, sfq, far_h2o, awet);
-    dry_absorb<NFC>(M, L, sfq, far_o2, adry);
+    const LineMasks lm = line_masks(M, sfq, NFC, lane);
+    h2o_absorb<NFC>(M, L, sfq, lm, awet);
+    dry_absorb<NFC>(M, L, sfq, lm, adry);
   }
   // neighbour level i-1: lane-1 through the crossbar, wave seams through a 2*NFC-double edge row
   if (lane == WAVE - 1) {
@@ -1112,10 +1295,9 @@ k_absorb(const AbsorbArgs A) {
   const double e = goff_gratch_e(ti, rhi);
   const LevelState L = level_state(pi, ti, e);
   const int lane = tid & (WAVE - 1);
-  const unsigned long long far_o2 = far_line_mask(sfq, NFC, M->n_o2, M->o2_f, FAR_MIN_GHZ + FAR_SHIFT_GHZ, lane);
-  const unsigned far_h2o = (unsigned)far_line_mask(sfq, NFC, M->n_h2o, M->h2o_fl, FAR_H2O_GHZ, lane);
-  h2o_absorb<NFC>(M, L, sfq, far_h2o, awet);
-  dry_absorb<NFC>(M, L, sfq, far_o2, adry);
+  const LineMasks lm = line_masks(M, sfq, NFC, lane);
+  h2o_absorb<NFC>(M, L, sfq, lm, awet);
+  dry_absorb<NFC>(M, L, sfq, lm, adry);
   if (active) {
 #pragma unroll
     for (int j = 0; j < NFC; ++j) {
