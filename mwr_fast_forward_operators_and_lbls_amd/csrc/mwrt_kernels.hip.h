@@ -137,6 +137,44 @@ __device__ __forceinline__ double flog(double x) {
 #endif
 }
 
+// exp(x) for |x| <= 1/16 with no range reduction: degree-9 Taylor (truncation 2.5e-19).  10 VALU.
+// Thin layers (tau * airmass <= 1/16) are the rule for the K-band channels at every level and angle.
+constexpr double EXP_SMALL_X = 0.0625;
+__device__ __forceinline__ double fexp_small(double x) {
+  double p = 2.7557319223985888e-06;                 // 1/9!
+  MWRT_FMA_SC(p, x, 2.4801587301587302e-05);         // 1/8!
+  MWRT_FMA_SC(p, x, 1.9841269841269841e-04);         // 1/7!
+  MWRT_FMA_SC(p, x, 1.3888888888888889e-03);         // 1/6!
+  MWRT_FMA_SC(p, x, 8.3333333333333332e-03);         // 1/5!
+  MWRT_FMA_SC(p, x, 4.1666666666666664e-02);         // 1/4!
+  MWRT_FMA_SC(p, x, 1.6666666666666666e-01);         // 1/3!
+  p = __builtin_fma(p, x, 0.5);
+  p = __builtin_fma(p, x, 1.0);
+  return __builtin_fma(p, x, 1.0);
+}
+
+// Planck function in pyrtlib's units, B = 1 / (exp(x) - 1), x = h f / (k T).  In the microwave x is a few
+// 1e-3: when the whole wave has x <= 1/32 the series (e^x - 1)/x = sum x^n/(n+1)! (8 terms, truncation
+// 2e-17) replaces exp-and-subtract -- 12 VALU instead of 27, and without the cancellation of exp(x) - 1
+// (which costs pyrtlib itself ~3e-14 relative; the difference is far below the parity bar).
+constexpr double PLANCK_SMALL_X = 0.03125;
+__device__ __forceinline__ double planck_b(double x) {
+  if (__all(x <= PLANCK_SMALL_X && x > 0.0)) {
+    double q = 2.4801587301587302e-05;                 // 1/8!
+    MWRT_FMA_SC(q, x, 1.9841269841269841e-04);         // 1/7!
+    MWRT_FMA_SC(q, x, 1.3888888888888889e-03);         // 1/6!
+    MWRT_FMA_SC(q, x, 8.3333333333333332e-03);         // 1/5!
+    MWRT_FMA_SC(q, x, 4.1666666666666664e-02);         // 1/4!
+    MWRT_FMA_SC(q, x, 1.6666666666666666e-01);         // 1/3!
+    q = __builtin_fma(q, x, 0.5);
+    q = __builtin_fma(q, x, 1.0);
+    const double em1 = q * x;
+    double r = __builtin_amdgcn_rcp(em1);
+    return __builtin_fma(r, __builtin_fma(-em1, r, 1.0), r);
+  }
+  return fdiv(1.0, fexp(x) - 1.0);
+}
+
 // inner-loop variant: one Newton step (v_rcp_f64 is good to ~2^-23, so ~2^-46 ~ 1.4e-14 relative)
 __device__ __forceinline__ double fdiv1(double x, double d) {
 #if MWRT_EXACT_DIV
@@ -168,12 +206,13 @@ struct LineMasks {
   unsigned long long o2_far;   // every chunk frequency >= FAR_MIN_GHZ + FAR_SHIFT_GHZ from the line centre
   unsigned h2o_far;            // ... >= FAR_H2O_GHZ from the line centre
   unsigned h2o_none;           // both Lorentz terms beyond the 750-GHz cutoff for every frequency (FAR_H2O_GHZ margin)
+  unsigned h2o_res;            // negative-frequency term beyond the cutoff for every frequency (e.g. 752 GHz from 22 GHz)
   unsigned h2o_sd;             // speed-dependent lines (W2 > 0)
 };
 
 template <class ModelPtr>
 __device__ __forceinline__ LineMasks line_masks(ModelPtr M, const double* sfq, int nslots, int lane) {
-  bool far_o = false, far_h = false, none_h = false, sd_h = false;
+  bool far_o = false, far_h = false, none_h = false, res_h = false, sd_h = false;
   const int n_o2 = M->n_o2, n_h2o = M->n_h2o;
   if (lane < n_o2) {
     const double c = M->o2_f[lane];
@@ -187,12 +226,14 @@ __device__ __forceinline__ LineMasks line_masks(ModelPtr M, const double* sfq, i
     for (int j = 0; j < nslots; ++j) { const double f = sfq[2 * j]; dmin = fmin(dmin, fabs(f - c)); smin = fmin(smin, fabs(f + c)); }
     far_h = dmin >= FAR_H2O_GHZ;
     none_h = dmin >= 750.0 + FAR_H2O_GHZ && smin >= 750.0 + FAR_H2O_GHZ;
+    res_h = smin >= 750.0 + FAR_H2O_GHZ;
     sd_h = M->h2o_w2[lane] > 0.0;
   }
   LineMasks lm;
   lm.o2_far = __ballot(far_o);
   lm.h2o_far = (unsigned)__ballot(far_h);
   lm.h2o_none = (unsigned)__ballot(none_h);
+  lm.h2o_res = (unsigned)__ballot(res_h);
   lm.h2o_sd = (unsigned)__ballot(sd_h);
   return lm;
 }
@@ -214,7 +255,7 @@ __device__ __forceinline__ cplx crecip(cplx b) {
   return {b.re * r, -b.im * r};
 }
 __device__ __forceinline__ cplx cdiv(cplx a, cplx b) { return cmul(a, crecip(b)); }
-// sqrt(x), x >= 0 finite and far from the denormal range: v_rsq_f64 seed (~2^-23) + one coupled
+// sqrt(x), x > 0 finite and far from the denormal range: v_rsq_f64 seed (~2^-23) + one coupled
 // Newton step on (g ~ sqrt x, h ~ 1/(2 sqrt x)) -> ~2^-45 relative
 __device__ __forceinline__ double fsqrt(double x) {
 #if MWRT_EXACT_DIV
@@ -223,8 +264,7 @@ __device__ __forceinline__ double fsqrt(double x) {
   const double y = __builtin_amdgcn_rsq(x);
   double g = x * y;
   const double h = 0.5 * y;
-  g = __builtin_fma(__builtin_fma(-g, g, x), h, g);
-  return (x > 0.0) ? g : 0.0;
+  return __builtin_fma(__builtin_fma(-g, g, x), h, g);      // x == 0 gives NaN: callers never use that lane
 #endif
 }
 __device__ __forceinline__ cplx csqrt_principal(cplx z) {
@@ -233,7 +273,7 @@ __device__ __forceinline__ cplx csqrt_principal(cplx z) {
   //   Re z >= 0: a = sqrt((r + Re z)/2), result (a, Im z / 2a);  Re z < 0: b = sqrt((r - Re z)/2), result (|Im z| / 2b, +-b)
   const bool pos = z.re >= 0.0;
   const double a = fsqrt(0.5 * (r + fabs(z.re)));
-  const double q = (a > 0.0) ? fdiv1(pos ? z.im : fabs(z.im), a + a) : 0.0;
+  const double q = fdiv1(pos ? z.im : fabs(z.im), a + a);    // z == 0 is outside the SD shape's domain (Re Xc > 0)
   return pos ? cplx{a, q} : cplx{q, copysign(a, z.im)};
 }
 
@@ -246,13 +286,15 @@ __device__ __forceinline__ cplx dcerror_upper(double x, double y) {
   const double b0 = 122.607931773875350, b1 = 352.730625110963558, b2 = 457.334478783897737,
                b3 = 348.703917719495792, b4 = 170.354001821091472, b5 = 53.992906912940207,
                b6 = 10.479857114260399;
-  cplx zh = {fabs(y), -x};
-  cplx as = {a6 * zh.re + a5, a6 * zh.im};
-  as = cadd(cmul(as, zh), a4); as = cadd(cmul(as, zh), a3); as = cadd(cmul(as, zh), a2);
-  as = cadd(cmul(as, zh), a1); as = cadd(cmul(as, zh), a0);
+  const cplx zh = {fabs(y), -x};
+  // one Horner step acc * zh + c (c real) in four FMA-class instructions
+  auto step = [&](cplx acc, double c) -> cplx {
+    return {__builtin_fma(acc.re, zh.re, __builtin_fma(-acc.im, zh.im, c)), __builtin_fma(acc.re, zh.im, acc.im * zh.re)};
+  };
+  cplx as = {__builtin_fma(a6, zh.re, a5), a6 * zh.im};
+  as = step(as, a4); as = step(as, a3); as = step(as, a2); as = step(as, a1); as = step(as, a0);
   cplx bs = {zh.re + b6, zh.im};
-  bs = cadd(cmul(bs, zh), b5); bs = cadd(cmul(bs, zh), b4); bs = cadd(cmul(bs, zh), b3);
-  bs = cadd(cmul(bs, zh), b2); bs = cadd(cmul(bs, zh), b1); bs = cadd(cmul(bs, zh), b0);
+  bs = step(bs, b5); bs = step(bs, b4); bs = step(bs, b3); bs = step(bs, b2); bs = step(bs, b1); bs = step(bs, b0);
   return cdiv(as, bs);
 }
 
@@ -338,7 +380,7 @@ __device__ __forceinline__ H2OLine h2o_line(cmodel M, int k, double pda, double 
   }
   q.wsq = q.w0 * q.w0;
   q.s = R.s1 * ti2 * fexp(R.b2 * (1.0 - ti));                 // R.s1 = S1 / fl^2: the f^2 is applied at the end
-  q.base = fdiv(q.w0, 562500.0 + q.wsq);
+  q.base = fdiv1(q.w0, 562500.0 + q.wsq);
   q.c1 = fl + shift;
   q.sw = q.s * q.w0;
   q.sbase = q.s * q.base;
@@ -417,8 +459,8 @@ __device__ __forceinline__ void h2o_absorb(cmodel M, const LevelState& L, const 
   // Lines whose two terms are beyond the cutoff for every frequency (e.g. 916 GHz from 22 GHz) are skipped.
   const double fmin = sfq[2 * NFC], fmax = sfq[2 * NFC + 1];
   double bsum = 0.0;                                          // sum of (count * s * base), frequency independent
-  unsigned deferred = ~lm.h2o_far & ~lm.h2o_sd & ~lm.h2o_none & all;
-  const unsigned setA = (MWRT_ABLATE & 2) ? 0u : (lm.h2o_far & ~lm.h2o_sd & ~lm.h2o_none & all);
+  unsigned deferred = (~lm.h2o_far | lm.h2o_res) & ~lm.h2o_sd & ~lm.h2o_none & all;
+  const unsigned setA = (MWRT_ABLATE & 2) ? 0u : (lm.h2o_far & ~lm.h2o_res & ~lm.h2o_sd & ~lm.h2o_none & all);
   // loop A walks its lines FOUR at a time (far_quad_accumulate); the count mod 4 left over joins loop B
   const unsigned leftA = (unsigned)lowest_bits(setA, __builtin_popcount(setA) & 3);
   deferred |= leftA;
@@ -513,20 +555,41 @@ __device__ __forceinline__ void h2o_absorb(cmodel M, const LevelState& L, const 
     const double xre = q.w0 - 1.5 * w2, xim0 = 1.5 * delta2;
     LDS_RELOAD_FENCE();
     // pass 1: the cutoff Lorentzians, the resonant one masked out where the SD shape takes over
+    const bool d1_in = (q.c1 - fmin < 750.0) && (fmax - q.c1 < 750.0) && (q.c1 - fmin > -750.0);
+    const bool d2_in = fmax + q.c1 < 750.0 && fmin + q.c1 > -750.0;
+    if (__all(d1_in && d2_in)) {                                // both inside the cutoff everywhere (22 / 183 GHz lines)
+      const double sbase2 = q.sbase + q.sbase;
 #pragma unroll
-    for (int j = 0; j < NFC; ++j) {
-      const double f = sfq[2 * j];
-      const double d1 = f - q.c1;
-      const double d2 = f + q.c1;
-      const double D1 = __builtin_fma(d1, d1, q.wsq);
-      const double D2 = __builtin_fma(d2, d2, q.wsq);
-      const double a1 = fabs(d1);
-      const double m1 = (a1 < 750.0 && !(a1 < sdlim)) ? 1.0 : 0.0;
-      const double m2 = (fabs(d2) < 750.0) ? 1.0 : 0.0;
-      const double num = __builtin_fma(m2, D1, m1 * D2);
-      const double r = fdiv1(num, D1 * D2);
-      sum[j] = __builtin_fma(r, q.sw, sum[j]);
-      sum[j] = __builtin_fma(-(m1 + m2), q.sbase, sum[j]);
+      for (int j = 0; j < NFC; ++j) {
+        const double f = sfq[2 * j];
+        const double d1 = f - q.c1;
+        const double d2 = f + q.c1;
+        const double D1 = __builtin_fma(d1, d1, q.wsq);
+        const double D2 = __builtin_fma(d2, d2, q.wsq);
+        const bool inner = fabs(d1) < sdlim;
+        const double den12 = D1 * D2;
+        double r = __builtin_amdgcn_rcp(den12);
+        r = __builtin_fma(r, __builtin_fma(-den12, r, 1.0), r);
+        const double num = inner ? D1 : D1 + D2;
+        sum[j] = __builtin_fma(num * r, q.sw, sum[j]);
+        sum[j] -= inner ? q.sbase : sbase2;
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < NFC; ++j) {
+        const double f = sfq[2 * j];
+        const double d1 = f - q.c1;
+        const double d2 = f + q.c1;
+        const double D1 = __builtin_fma(d1, d1, q.wsq);
+        const double D2 = __builtin_fma(d2, d2, q.wsq);
+        const double a1 = fabs(d1);
+        const double m1 = (a1 < 750.0 && !(a1 < sdlim)) ? 1.0 : 0.0;
+        const double m2 = (fabs(d2) < 750.0) ? 1.0 : 0.0;
+        const double num = __builtin_fma(m2, D1, m1 * D2);
+        const double r = fdiv1(num, D1 * D2);
+        sum[j] = __builtin_fma(r, q.sw, sum[j]);
+        sum[j] = __builtin_fma(-(m1 + m2), q.sbase, sum[j]);
+      }
     }
     // pass 2: the SD resonant shape, frequency by frequency, only where some lane of the wave is inside
     // 10 half-widths (the branch is wave-uniform, so nothing of one frequency interleaves with the next)
@@ -880,11 +943,12 @@ k_tb_fused(const FusedArgs A) {
     if (nfk <= 0) break;
     if (h > 0) __syncthreads();                          // previous pass has finished reading LDS
     if (active) {
+      const double hkt = fdiv(hk, ti);                  // h / (k T) per GHz
 #pragma unroll
       for (int jj = 0; jj < NFK; ++jj) {
         const int j = h * NFK + jj;
         tau[jj * ld + tid] = tw[j] + td[j];
-        bof[jj * ld + tid] = fdiv(1.0, fexp(fdiv(sfq[2 * j] * hk, ti)) - 1.0);
+        bof[jj * ld + tid] = planck_b(sfq[2 * j] * hkt);
       }
     }
     // optional zenith opacity sums (tauwet / taudry columns); deterministic order
@@ -914,9 +978,9 @@ k_tb_fused(const FusedArgs A) {
       double bprev = (lo < nlev) ? bj[lo - 1] : 0.0;
       for (int i = lo; i < hi; ++i) {
         const double tl = tj[i] * am;
-        const double E = fexp(-tl);
+        const double E = __all(fabs(tl) <= EXP_SMALL_X) ? fexp_small(-tl) : fexp(-tl);
         const double bi = bj[i];
-        const double lay = fdiv(__builtin_fma(bi, E, bprev), 1.0 + E);
+        const double lay = fdiv1(__builtin_fma(bi, E, bprev), 1.0 + E);
         B = __builtin_fma(lay * T, 1.0 - E, B);
         T *= E;
         S += tl;
