@@ -24,7 +24,8 @@
  *   tb_out     [nprof][nang][nf]  == pyrtlib's DataFrame row order (angle-major) per profile
  *   valid_out  [nprof] 1 = ok; 0 = NaN in the inputs of that profile (the wrapper's
  *              check_for_nans, :71-79, :117-119: outputs stay NaN); 2 = negative absorption
- *              met in the layer integration (pyrtlib raises ValueError there).
+ *              met in the layer integration (pyrtlib raises ValueError there); 3 = a ray of this
+ *              profile was trapped (ducting) while ray tracing (that angle's outputs are NaN).
  *
  * NaN rules (check_for_nans is evaluated per (time, Crop, elevation), :101-119):
  *   NaN in a profile's z/p/T/rh   -> that profile's outputs NaN, valid = 0;
@@ -62,7 +63,7 @@
 extern "C" {
 #endif
 
-#define MWRT_VERSION 100          /* 0.1.0 */
+#define MWRT_VERSION 200          /* 0.2.0: mwrt_tb_options, tauliq / tauice extras, liq_mode, MWRT_STREAM_LEGACY */
 #define MWRT_MAX_H2O_LINES 32
 #define MWRT_MAX_O2_LINES 64
 #define MWRT_MAX_LEVELS 1024      /* one lane per level, one workgroup per profile */
@@ -87,7 +88,7 @@ typedef struct mwrt_model_desc {
   int32_t o2_line1_dens;    /* R98: 118.75-GHz width uses DENS (first-order mixing mode only) */
   int32_t n2_fdep;          /* absn2 frequency-dependence factor on/off */
   int32_t n2_ptot;          /* 1: N2 at total pressure (pre-2019, folded into the O2 routine) */
-  int32_t reserved0;
+  int32_t liq_mode;         /* cloud liquid (opt-in): 0 Liebe 1991 / MPM93 double Debye; 1 Rosenkranz 2015 */
   double h2o_reftcon, h2o_reftline, h2o_cf, h2o_xcf, h2o_cs, h2o_xcs, h2o_pvap_div, h2o_den_coef;
   double o2_x, o2_wb300, o2_pvap_div, o2_wv_factor, o2_nonres, o2_coef;
   double n2_l, n2_m, n2_n;
@@ -114,8 +115,28 @@ typedef struct mwrt_tb_extras {
   double* tmr;      /* [nprof][nang][nf] */
   double* tauwet;   /* [nprof][nang][nf] slant-path opacity, Np */
   double* taudry;   /* [nprof][nang][nf] */
-  double* taulay;   /* [nprof][nf][nlev] ZENITH layer optical depth (wet+dry), entry 0 = 0 */
+  double* taulay;   /* [nprof][nf][nlev] ZENITH layer optical depth (wet+dry+ice+liquid), entry 0 = 0 */
+  double* tauliq;   /* [nprof][nang][nf] cloud liquid opacity (0 unless mwrt_tb_options.denliq is given) */
+  double* tauice;   /* [nprof][nang][nf] cloud ice opacity */
 } mwrt_tb_extras;
+
+/* Physics pyrtlib offers and the reference leaves at its defaults (TbCloudRTE(..., ray_tracing=False,
+ * cloudy=False); the author prints rte.cloudy at old_processing.py:558-563).  STRICTLY OPT-IN: a NULL
+ * options pointer, or all-zero options, is the reference's clear-sky plane-parallel path bit for bit.
+ *   denliq / denice  cloud liquid / ice density profiles [nprof][nlev] in g m-3 (what init_cloudy takes);
+ *                    the upstream producer stores kg/kg: python_src/preproc/derive_cloud_water.py:68-142,
+ *                    preprocessing4all.py:811-812, :1199-1200 ("Level_Liquid", "Level_Ice").
+ *                    RTEquation.cloudy_absorption + exponential_integration(zeroflg = False).
+ *   ray_tracing      != 0: spherical refracted slant paths (RTEquation.refractivity, Thayer 1974, and
+ *                    RTEquation.ray_tracing, TBMODEL RAYTRAC) instead of dz / sin(elev) -- matters for the
+ *                    4.2 ... 8.4 degree elevations of PyRTlib_processing.py:37.
+ * On the *_device entry point denliq / denice are DEVICE pointers. */
+typedef struct mwrt_tb_options {
+  const double* denliq;
+  const double* denice;
+  int32_t ray_tracing;
+  int32_t reserved0;
+} mwrt_tb_options;
 
 typedef struct mwrt_context mwrt_context;   /* one per (host thread, GPU): device, stream, workspace */
 typedef struct mwrt_model mwrt_model;       /* device-resident copy of an mwrt_model_desc */
@@ -153,6 +174,21 @@ int mwrt_tb_batch_device(mwrt_context* ctx, const mwrt_model* model,
                          int32_t nang, const double* elev_deg,
                          double* d_tb_out, uint8_t* d_valid_out, const mwrt_tb_extras* d_extras,
                          void* stream);
+
+/* mwrt_tb_batch / mwrt_tb_batch_device with the opt-in physics of mwrt_tb_options (NULL = none). */
+int mwrt_tb_batch_opt(mwrt_context* ctx, const mwrt_model* model,
+                      int64_t nprof, int32_t nlev,
+                      const double* z_km, const double* p_hpa, const double* t_k, const double* rh_frac,
+                      int32_t nf, const double* frq_ghz, int32_t nang, const double* elev_deg,
+                      double* tb_out, uint8_t* valid_out, const mwrt_tb_extras* extras,
+                      const mwrt_tb_options* options);
+int mwrt_tb_batch_opt_device(mwrt_context* ctx, const mwrt_model* model,
+                             int64_t nprof, int32_t nlev,
+                             const double* d_z_km, const double* d_p_hpa, const double* d_t_k,
+                             const double* d_rh_frac,
+                             int32_t nf, const double* frq_ghz, int32_t nang, const double* elev_deg,
+                             double* d_tb_out, uint8_t* d_valid_out, const mwrt_tb_extras* d_extras,
+                             const mwrt_tb_options* d_options, void* stream);
 
 /* Several absorption models over the SAME profiles in one launch (and one host->device copy): what
  * the wrapper does four times per profile, R20/R24/R17/R98 (PyRTlib_processing.py:121-151).

@@ -32,7 +32,17 @@ class NativeLibraryMissing(ImportError):
 
 class MwrtTbExtras(ctypes.Structure):
     _fields_ = [("tbatm", ctypes.c_void_p), ("tmr", ctypes.c_void_p), ("tauwet", ctypes.c_void_p),
-                ("taudry", ctypes.c_void_p), ("taulay", ctypes.c_void_p)]
+                ("taudry", ctypes.c_void_p), ("taulay", ctypes.c_void_p), ("tauliq", ctypes.c_void_p),
+                ("tauice", ctypes.c_void_p)]
+
+
+class MwrtTbOptions(ctypes.Structure):
+    """include/mwrt.h mwrt_tb_options: the opt-in physics (cloud liquid / ice, ray tracing)."""
+    _fields_ = [("denliq", ctypes.c_void_p), ("denice", ctypes.c_void_p), ("ray_tracing", ctypes.c_int32),
+                ("reserved0", ctypes.c_int32)]
+
+
+MWRT_VERSION = 200
 
 
 #: every symbol include/mwrt.h declares: (name, restype, argtypes)
@@ -50,6 +60,11 @@ SIGNATURES = {
                                      _vp, _vp, ctypes.POINTER(MwrtTbExtras)]),
     "mwrt_tb_batch_device": (ctypes.c_int, [_vp, _vp, _i64, _i32, _vp, _vp, _vp, _vp, _i32, _vp, _i32, _vp,
                                             _vp, _vp, ctypes.POINTER(MwrtTbExtras), _vp]),
+    "mwrt_tb_batch_opt": (ctypes.c_int, [_vp, _vp, _i64, _i32, _vp, _vp, _vp, _vp, _i32, _vp, _i32, _vp,
+                                         _vp, _vp, ctypes.POINTER(MwrtTbExtras), ctypes.POINTER(MwrtTbOptions)]),
+    "mwrt_tb_batch_opt_device": (ctypes.c_int, [_vp, _vp, _i64, _i32, _vp, _vp, _vp, _vp, _i32, _vp, _i32, _vp,
+                                                _vp, _vp, ctypes.POINTER(MwrtTbExtras), ctypes.POINTER(MwrtTbOptions),
+                                                _vp]),
     "mwrt_tb_batch_multi": (ctypes.c_int, [_vp, _i32, ctypes.POINTER(_vp), _i64, _i32, _vp, _vp, _vp, _vp, _i32, _vp,
                                            _i32, _vp, _vp, _vp]),
     "mwrt_tb_batch_multi_device": (ctypes.c_int, [_vp, _i32, ctypes.POINTER(_vp), _i64, _i32, _vp, _vp, _vp, _vp, _i32,
@@ -112,6 +127,9 @@ def load_library(path: Optional[str] = None) -> ctypes.CDLL:
             fn.restype, fn.argtypes = res, args
         if lib.mwrt_model_desc_size() != ctypes.sizeof(MwrtModelDesc):
             raise NativeLibraryMissing("mwrt_model_desc layout mismatch between libmwrt.so and spectroscopy.py")
+        if lib.mwrt_version() != MWRT_VERSION:
+            raise NativeLibraryMissing(f"libmwrt.so is version {lib.mwrt_version()}, this binding needs {MWRT_VERSION}: "
+                                       "rebuild (python -c 'import __graft_entry__ as g; g.build()')")
         if path is None:
             _lib = lib
         return lib
@@ -220,8 +238,11 @@ class Context:
 
     # -- host-buffer entry points ------------------------------------------------------------
     @_serialised
-    def tb_batch(self, model, z, p, t, rh, frq, elev, extras=False):
-        """[nprof][nlev] profiles (ground->top) -> tb [nprof][nang][nf], valid [nprof] (+ extras dict)."""
+    def tb_batch(self, model, z, p, t, rh, frq, elev, extras=False, denliq=None, denice=None, ray_tracing=False):
+        """[nprof][nlev] profiles (ground->top) -> tb [nprof][nang][nf], valid [nprof] (+ extras dict).
+
+        ``denliq`` / ``denice`` ([nprof][nlev], g m-3) and ``ray_tracing`` are the opt-in physics of
+        ``mwrt_tb_options``; left at their defaults the call is the reference's clear-sky plane-parallel path."""
         z = _f64(z)
         if z.ndim != 2:
             raise ValueError("profiles must be [nprof][nlev]")
@@ -233,13 +254,21 @@ class Context:
         valid = np.empty(nprof, dtype=np.uint8)
         ex, exs = None, None
         if extras:
-            ex = {k: np.empty((nprof, nang, nf)) for k in ("tbatm", "tmr", "tauwet", "taudry")}
+            ex = {k: np.empty((nprof, nang, nf)) for k in ("tbatm", "tmr", "tauwet", "taudry", "tauliq", "tauice")}
             ex["taulay"] = np.empty((nprof, nf, nlev))
-            exs = MwrtTbExtras(*[ex[k].ctypes.data for k in ("tbatm", "tmr", "tauwet", "taudry", "taulay")])
-        self._check(self._lib.mwrt_tb_batch(
+            exs = MwrtTbExtras(*[ex[k].ctypes.data for k in ("tbatm", "tmr", "tauwet", "taudry", "taulay", "tauliq",
+                                                              "tauice")])
+        opts = None
+        if denliq is not None or denice is not None or ray_tracing:
+            dl = None if denliq is None else _f64(denliq, z.shape, "denliq")
+            di = None if denice is None else _f64(denice, z.shape, "denice")
+            opts = MwrtTbOptions(dl.ctypes.data if dl is not None else None, di.ctypes.data if di is not None else None,
+                                 int(bool(ray_tracing)), 0)
+        self._check(self._lib.mwrt_tb_batch_opt(
             self._handle, self.model(model), nprof, nlev, _ptr(z), _ptr(p), _ptr(t), _ptr(rh),
             nf, _ptr(frq), nang, _ptr(elev), _ptr(tb), _ptr(valid),
-            ctypes.byref(exs) if exs is not None else None), "mwrt_tb_batch")
+            ctypes.byref(exs) if exs is not None else None,
+            ctypes.byref(opts) if opts is not None else None), "mwrt_tb_batch_opt")
         return (tb, valid, ex) if extras else (tb, valid)
 
     @_serialised
@@ -285,13 +314,23 @@ class Context:
     # -- device-buffer entry points (raw device addresses, e.g. torch.Tensor.data_ptr()) -------
     @_serialised
     def tb_batch_device(self, model, nprof, nlev, d_z, d_p, d_t, d_rh, frq, elev, d_tb, d_valid,
-                        extras: Optional[MwrtTbExtras] = None, stream=None):
+                        extras: Optional[MwrtTbExtras] = None, stream=None, d_denliq=None, d_denice=None,
+                        ray_tracing=False):
         frq, elev = _f64(frq).ravel(), _f64(elev).ravel()
-        self._check(self._lib.mwrt_tb_batch_device(
+        if d_denliq is None and d_denice is None and not ray_tracing:
+            self._check(self._lib.mwrt_tb_batch_device(
+                self._handle, self.model(model), int(nprof), int(nlev), _ptr(d_z), _ptr(d_p), _ptr(d_t), _ptr(d_rh),
+                frq.size, _ptr(frq), elev.size, _ptr(elev), _ptr(d_tb), _ptr(d_valid),
+                ctypes.byref(extras) if extras is not None else None,
+                _stream(stream)), "mwrt_tb_batch_device")
+            return
+        opts = MwrtTbOptions(int(d_denliq) if d_denliq is not None else None,
+                             int(d_denice) if d_denice is not None else None, int(bool(ray_tracing)), 0)
+        self._check(self._lib.mwrt_tb_batch_opt_device(
             self._handle, self.model(model), int(nprof), int(nlev), _ptr(d_z), _ptr(d_p), _ptr(d_t), _ptr(d_rh),
             frq.size, _ptr(frq), elev.size, _ptr(elev), _ptr(d_tb), _ptr(d_valid),
-            ctypes.byref(extras) if extras is not None else None,
-            _stream(stream)), "mwrt_tb_batch_device")
+            ctypes.byref(extras) if extras is not None else None, ctypes.byref(opts),
+            _stream(stream)), "mwrt_tb_batch_opt_device")
 
     @_serialised
     def absorption_batch_device(self, model, nprof, nlev, d_p, d_t, d_rh, frq, d_awet, d_adry, stream=None):

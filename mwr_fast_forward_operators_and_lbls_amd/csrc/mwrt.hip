@@ -90,7 +90,9 @@ struct mwrt_context {
   // small per-call parameter arrays (frq, airmass): content-keyed device copies.  A copy is never
   // overwritten or freed while the context lives (bar LRU eviction behind a device-wide drain), so
   // launches still queued on ANY stream and captured hipGraphs keep reading valid memory.
-  ParamCache frq_cache, am_cache;
+  ParamCache frq_cache, am_cache, elev_cache;
+  // ray-tracing workspace: path factors [nprof][nang][nlev] and the per-profile ducting flag
+  DevBuf d_amf, d_duct;
   // staging for the host-buffer entry points
   DevBuf d_in, d_out, d_valid, d_ex;
   // timing: a ring of hipEvent pairs recorded around every kernel launch, on the launch stream
@@ -174,12 +176,18 @@ void timing_end(mwrt_context* c, hipStream_t st) {
   if (c->timing) { (void)hipEventRecord(c->ev1[c->ev_count % TIMING_RING], st); c->ev_count++; }
 }
 
+template <int NFC, int MAXT, bool OPT>
+int launch_fused_inst(const FusedArgs& a, dim3 grid, dim3 block, size_t lds, hipStream_t st) {
+  auto k = k_tb_fused<NFC, (NFC == 14 ? 7 : 8), MAXT, OPT>;
+  HIP_TRY(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  hipLaunchKernelGGL(k, grid, block, lds, st, a);
+  return MWRT_OK;
+}
+
 template <int NFC>
-int launch_fused(mwrt_context* c, FusedArgs a, int64_t nprof, hipStream_t st) {
+int launch_fused(mwrt_context* c, FusedArgs a, int64_t nprof, hipStream_t st, bool opt) {
   const int threads = ((a.nlev + WAVE - 1) / WAVE) * WAVE;
   const int nchunks = (a.nf + NFC - 1) / NFC;
-  const int npairs = std::min(NFC, a.nf) * a.nang;
-  (void)npairs;
   size_t lds = 0;
   if (!plan_fused(c, NFC, a.nlev, a.nf, a.nang, &a.g, &lds))
     return fail(MWRT_ERR_UNSUPPORTED, "LDS budget exceeded (nlev x nang too large)");
@@ -189,16 +197,13 @@ int launch_fused(mwrt_context* c, FusedArgs a, int64_t nprof, hipStream_t st) {
   a.write_valid = nchunks == 1;
   if (!a.write_valid) HIP_TRY(hipMemsetAsync(a.valid, 1, (size_t)nprof, st));
   timing_begin(c, st);
-  if (threads <= 256) {
-    auto k = k_tb_fused<NFC, (NFC == 14 ? 7 : 8), 256>;
-    HIP_TRY(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(k, grid, block, lds, st, a);
-  } else {
-    auto k = k_tb_fused<NFC, (NFC == 14 ? 7 : 8), 1024>;
-    HIP_TRY(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(k, grid, block, lds, st, a);
-  }
+  int rc;
+  if (threads <= 256) rc = opt ? launch_fused_inst<NFC, 256, true>(a, grid, block, lds, st)
+                               : launch_fused_inst<NFC, 256, false>(a, grid, block, lds, st);
+  else rc = opt ? launch_fused_inst<NFC, 1024, true>(a, grid, block, lds, st)
+                : launch_fused_inst<NFC, 1024, false>(a, grid, block, lds, st);
   timing_end(c, st);
+  if (rc) return rc;
   HIP_TRY(hipGetLastError());
   return MWRT_OK;
 }
@@ -315,7 +320,8 @@ int mwrt_destroy(mwrt_context* c) {
   if (!c) return MWRT_OK;
   (void)hipSetDevice(c->device);
   (void)hipStreamSynchronize(c->stream);
-  c->frq_cache.release(); c->am_cache.release(); c->d_in.release(); c->d_out.release();
+  c->frq_cache.release(); c->am_cache.release(); c->elev_cache.release(); c->d_amf.release(); c->d_duct.release();
+  c->d_in.release(); c->d_out.release();
   c->d_valid.release(); c->d_ex.release();
   for (hipEvent_t e : c->ev0) (void)hipEventDestroy(e);
   for (hipEvent_t e : c->ev1) (void)hipEventDestroy(e);
@@ -370,8 +376,12 @@ int mwrt_model_destroy(mwrt_context* c, mwrt_model* m) {
 static int tb_launch(mwrt_context* c, int nmodels, const mwrt_model* const* ms, int64_t nprof, int32_t nlev,
                      const double* d_z, const double* d_p, const double* d_t, const double* d_rh,
                      int32_t nf, const double* frq, int32_t nang, const double* elev,
-                     double* d_tb, uint8_t* d_valid, const mwrt_tb_extras* ex, void* stream) {
+                     double* d_tb, uint8_t* d_valid, const mwrt_tb_extras* ex, void* stream,
+                     const mwrt_tb_options* opt = nullptr) {
   if (nmodels < 1 || nmodels > MAX_MULTI || !ms) return fail(MWRT_ERR_INVALID_ARGUMENT, "nmodels must be 1..8");
+  const bool cloudy = opt && (opt->denliq || opt->denice);
+  const bool rays = opt && opt->ray_tracing != 0;
+  const bool use_opt = cloudy || rays;
   for (int i = 0; i < nmodels; ++i) {
     int rc = check_common(c, ms[i], nprof, nlev, nf);
     if (rc) return rc;
@@ -398,6 +408,8 @@ static int tb_launch(mwrt_context* c, int nmodels, const mwrt_model* const* ms, 
       if (ex->tauwet) HIP_TRY(hipMemsetAsync(ex->tauwet, 0xFF, nout * sizeof(double), st));
       if (ex->taudry) HIP_TRY(hipMemsetAsync(ex->taudry, 0xFF, nout * sizeof(double), st));
       if (ex->taulay) HIP_TRY(hipMemsetAsync(ex->taulay, 0xFF, (size_t)rows * nf * nlev * sizeof(double), st));
+      if (ex->tauliq) HIP_TRY(hipMemsetAsync(ex->tauliq, 0xFF, nout * sizeof(double), st));
+      if (ex->tauice) HIP_TRY(hipMemsetAsync(ex->tauice, 0xFF, nout * sizeof(double), st));
     }
     return MWRT_OK;
   }
@@ -422,6 +434,7 @@ static int tb_launch(mwrt_context* c, int nmodels, const mwrt_model* const* ms, 
   const bool spectral = c->kernel_policy == 2;
   if (spectral) {
     if (nmodels != 1) return fail(MWRT_ERR_UNSUPPORTED, "the spectral kernel evaluates one model per launch");
+    if (use_opt) return fail(MWRT_ERR_UNSUPPORTED, "cloud / ray-tracing options need the fused kernel (policy 0 or 1)");
     SpectralArgs sa{};
     sa.M = ms[0]->d_desc; sa.z = d_z; sa.p = d_p; sa.t = d_t; sa.rh = d_rh;
     sa.frq = dev_frq; sa.airmass = dev_am;
@@ -438,10 +451,36 @@ static int tb_launch(mwrt_context* c, int nmodels, const mwrt_model* const* ms, 
   a.tb = d_tb; a.valid = d_valid;
   if (ex) { a.tbatm = ex->tbatm; a.tmr = ex->tmr; a.tauwet = ex->tauwet; a.taudry = ex->taudry; a.taulay = ex->taulay; }
   a.nlev = nlev; a.nf = nf; a.nang = nang;
+  if (ex) { a.tauliq = ex->tauliq; a.tauice = ex->tauice; }
+  if (!use_opt && ex) {                               // clear sky: the cloud columns are plain zeros
+    if (ex->tauliq) HIP_TRY(hipMemsetAsync(ex->tauliq, 0, nout * sizeof(double), st));
+    if (ex->tauice) HIP_TRY(hipMemsetAsync(ex->tauice, 0, nout * sizeof(double), st));
+    a.tauliq = nullptr; a.tauice = nullptr;
+  }
+  if (cloudy) { a.denliq = opt->denliq; a.denice = opt->denice; }
+  if (rays) {
+    // RTEquation.refractivity + ray_tracing [EXT] as a pre-kernel on the same stream: path factor ds/dz per
+    // (profile, angle, layer) into the context's workspace (grown only, never shrunk)
+    const double* dev_elev = nullptr;
+    rc = upload_small(c, c->elev_cache, elev, nang, &dev_elev); if (rc) return rc;
+    const size_t need = (size_t)nprof * nang * nlev * sizeof(double);
+    if (need > c->d_amf.cap || (size_t)nprof > c->d_duct.cap) {
+      HIP_TRY(hipDeviceSynchronize());                // queued launches may still read the old workspace
+      HIP_TRY(c->d_amf.reserve(need));
+      HIP_TRY(c->d_duct.reserve((size_t)nprof));
+    }
+    HIP_TRY(hipMemsetAsync(c->d_duct.p, 0, (size_t)nprof, st));
+    const int64_t nrays = nprof * nang;
+    hipLaunchKernelGGL(k_ray_paths, dim3((unsigned)((nrays + 63) / 64)), dim3(64), 0, st, d_z, d_p, d_t, d_rh, nprof,
+                       (int)nlev, dev_elev, (int)nang, c->d_amf.as<double>(), c->d_duct.as<uint8_t>());
+    HIP_TRY(hipGetLastError());
+    a.amf = c->d_amf.as<double>();
+    a.duct = c->d_duct.as<uint8_t>();
+  }
   switch (pick_nfc_fused(c, nlev, nf, nang)) {
-    case 8: return launch_fused<8>(c, a, rows, st);
-    case 14: return launch_fused<14>(c, a, rows, st);
-    default: return launch_fused<16>(c, a, rows, st);
+    case 8: return launch_fused<8>(c, a, rows, st, use_opt);
+    case 14: return launch_fused<14>(c, a, rows, st, use_opt);
+    default: return launch_fused<16>(c, a, rows, st, use_opt);
   }
 }
 
@@ -451,6 +490,15 @@ int mwrt_tb_batch_device(mwrt_context* c, const mwrt_model* m, int64_t nprof, in
                          double* d_tb, uint8_t* d_valid, const mwrt_tb_extras* ex, void* stream) {
   if (!c || !m) return fail(MWRT_ERR_INVALID_ARGUMENT, "null context or model");
   return tb_launch(c, 1, &m, nprof, nlev, d_z, d_p, d_t, d_rh, nf, frq, nang, elev, d_tb, d_valid, ex, stream);
+}
+
+int mwrt_tb_batch_opt_device(mwrt_context* c, const mwrt_model* m, int64_t nprof, int32_t nlev,
+                             const double* d_z, const double* d_p, const double* d_t, const double* d_rh,
+                             int32_t nf, const double* frq, int32_t nang, const double* elev,
+                             double* d_tb, uint8_t* d_valid, const mwrt_tb_extras* ex, const mwrt_tb_options* opt,
+                             void* stream) {
+  if (!c || !m) return fail(MWRT_ERR_INVALID_ARGUMENT, "null context or model");
+  return tb_launch(c, 1, &m, nprof, nlev, d_z, d_p, d_t, d_rh, nf, frq, nang, elev, d_tb, d_valid, ex, stream, opt);
 }
 
 int mwrt_tb_batch_multi_device(mwrt_context* c, int32_t nmodels, const mwrt_model* const* models, int64_t nprof,
@@ -496,6 +544,13 @@ int mwrt_tb_batch(mwrt_context* c, const mwrt_model* m, int64_t nprof, int32_t n
                   const double* z, const double* p, const double* t, const double* rh,
                   int32_t nf, const double* frq, int32_t nang, const double* elev,
                   double* tb, uint8_t* valid, const mwrt_tb_extras* ex) {
+  return mwrt_tb_batch_opt(c, m, nprof, nlev, z, p, t, rh, nf, frq, nang, elev, tb, valid, ex, nullptr);
+}
+
+int mwrt_tb_batch_opt(mwrt_context* c, const mwrt_model* m, int64_t nprof, int32_t nlev,
+                      const double* z, const double* p, const double* t, const double* rh,
+                      int32_t nf, const double* frq, int32_t nang, const double* elev,
+                      double* tb, uint8_t* valid, const mwrt_tb_extras* ex, const mwrt_tb_options* opt) {
   int rc = check_common(c, m, nprof, nlev, nf);
   if (rc) return rc;
   if (nang < 1 || nang > MWRT_MAX_ANGLES) return fail(MWRT_ERR_INVALID_ARGUMENT, "nang out of range");
@@ -505,34 +560,44 @@ int mwrt_tb_batch(mwrt_context* c, const mwrt_model* m, int64_t nprof, int32_t n
   hipStream_t st = c->stream;
   const size_t nin = (size_t)nprof * nlev, nout = (size_t)nprof * nang * nf;
   const size_t nlay = (size_t)nprof * nf * nlev;
-  HIP_TRY(c->d_in.reserve(4 * nin * sizeof(double)));
+  const bool has_liq = opt && opt->denliq, has_ice = opt && opt->denice;
+  HIP_TRY(c->d_in.reserve((4 + (has_liq ? 1 : 0) + (has_ice ? 1 : 0)) * nin * sizeof(double)));
   HIP_TRY(c->d_out.reserve(nout * sizeof(double)));
   HIP_TRY(c->d_valid.reserve((size_t)nprof));
   double* din = c->d_in.as<double>();
   const double* src[4] = {z, p, t, rh};
   for (int k = 0; k < 4; ++k)
     HIP_TRY(hipMemcpyAsync(din + k * nin, src[k], nin * sizeof(double), hipMemcpyHostToDevice, st));
+  mwrt_tb_options dopt{};
+  if (opt) {
+    double* q = din + 4 * nin;
+    if (has_liq) { HIP_TRY(hipMemcpyAsync(q, opt->denliq, nin * sizeof(double), hipMemcpyHostToDevice, st)); dopt.denliq = q; q += nin; }
+    if (has_ice) { HIP_TRY(hipMemcpyAsync(q, opt->denice, nin * sizeof(double), hipMemcpyHostToDevice, st)); dopt.denice = q; }
+    dopt.ray_tracing = opt->ray_tracing;
+  }
+  constexpr int NEX = 7;                               // tbatm tmr tauwet taudry taulay tauliq tauice
   mwrt_tb_extras dex{};
-  double* host_ex[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+  double* host_ex[NEX] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  double** slots[NEX] = {&dex.tbatm, &dex.tmr, &dex.tauwet, &dex.taudry, &dex.taulay, &dex.tauliq, &dex.tauice};
+  auto exlen = [&](int k) { return k == 4 ? nlay : nout; };
   if (ex) {
     host_ex[0] = ex->tbatm; host_ex[1] = ex->tmr; host_ex[2] = ex->tauwet; host_ex[3] = ex->taudry; host_ex[4] = ex->taulay;
+    host_ex[5] = ex->tauliq; host_ex[6] = ex->tauice;
     size_t need = 0;
-    for (int k = 0; k < 4; ++k) if (host_ex[k]) need += nout;
-    if (host_ex[4]) need += nlay;
+    for (int k = 0; k < NEX; ++k) if (host_ex[k]) need += exlen(k);
     HIP_TRY(c->d_ex.reserve(need * sizeof(double) + 8));
     double* q = c->d_ex.as<double>();
-    double** slots[5] = {&dex.tbatm, &dex.tmr, &dex.tauwet, &dex.taudry, &dex.taulay};
-    for (int k = 0; k < 5; ++k) if (host_ex[k]) { *slots[k] = q; q += (k < 4 ? nout : nlay); }
+    for (int k = 0; k < NEX; ++k) if (host_ex[k]) { *slots[k] = q; q += exlen(k); }
   }
-  rc = mwrt_tb_batch_device(c, m, nprof, nlev, din, din + nin, din + 2 * nin, din + 3 * nin, nf, frq, nang, elev,
-                            c->d_out.as<double>(), c->d_valid.as<uint8_t>(), ex ? &dex : nullptr, st);
+  rc = mwrt_tb_batch_opt_device(c, m, nprof, nlev, din, din + nin, din + 2 * nin, din + 3 * nin, nf, frq, nang, elev,
+                                c->d_out.as<double>(), c->d_valid.as<uint8_t>(), ex ? &dex : nullptr, opt ? &dopt : nullptr,
+                                st);
   if (rc) return rc;
   HIP_TRY(hipMemcpyAsync(tb, c->d_out.p, nout * sizeof(double), hipMemcpyDeviceToHost, st));
   HIP_TRY(hipMemcpyAsync(valid, c->d_valid.p, (size_t)nprof, hipMemcpyDeviceToHost, st));
   if (ex) {
-    double* dptr[5] = {dex.tbatm, dex.tmr, dex.tauwet, dex.taudry, dex.taulay};
-    for (int k = 0; k < 5; ++k)
-      if (host_ex[k]) HIP_TRY(hipMemcpyAsync(host_ex[k], dptr[k], (k < 4 ? nout : nlay) * sizeof(double), hipMemcpyDeviceToHost, st));
+    for (int k = 0; k < NEX; ++k)
+      if (host_ex[k]) HIP_TRY(hipMemcpyAsync(host_ex[k], *slots[k], exlen(k) * sizeof(double), hipMemcpyDeviceToHost, st));
   }
   HIP_TRY(hipStreamSynchronize(st));
   // a profile flagged 2 (negative absorption: pyrtlib raises for the whole execute()) is blanked
@@ -540,11 +605,12 @@ int mwrt_tb_batch(mwrt_context* c, const mwrt_model* m, int64_t nprof, int32_t n
   const double qnan = std::nan("");
   for (int64_t i = 0; i < nprof; ++i) {
     if (valid[i] != 2) continue;
-    for (size_t o = 0; o < (size_t)nang * nf; ++o) {
-      tb[(size_t)i * nang * nf + o] = qnan;
-      for (int k = 0; k < 4; ++k) if (host_ex[k]) host_ex[k][(size_t)i * nang * nf + o] = qnan;
+    for (size_t o = 0; o < (size_t)nang * nf; ++o) tb[(size_t)i * nang * nf + o] = qnan;
+    for (int k = 0; k < NEX; ++k) {
+      if (!host_ex[k]) continue;
+      const size_t per = k == 4 ? (size_t)nf * nlev : (size_t)nang * nf;
+      for (size_t o = 0; o < per; ++o) host_ex[k][(size_t)i * per + o] = qnan;
     }
-    if (host_ex[4]) for (size_t o = 0; o < (size_t)nf * nlev; ++o) host_ex[4][(size_t)i * nf * nlev + o] = qnan;
   }
   return MWRT_OK;
 }

@@ -754,6 +754,7 @@ __device__ __forceinline__ void dry_absorb(cmodel M, const LevelState& L, const 
 // (frexp, second division, series) and a third division.  It is also better conditioned than the
 // quotient form, which loses up to 1e-7 relative when x1 - x0 is just above the 1e-9 switch.
 constexpr double LOGMEAN_SMALL_S = 0.1715;      // |s| <= this: series truncation s^22/23 < 7e-19
+template <bool ZEROFLG = true>
 __device__ __forceinline__ double layer_value(double x1, double x0, bool& neg) {
   const double d = x1 - x0;
   const double sm = x1 + x0;
@@ -782,10 +783,175 @@ __device__ __forceinline__ double layer_value(double x1, double x0, bool& neg) {
     r = fdiv1(d, flog(fdiv(x1, x0)));
   }
   if (negative) neg = true;
-  r = zero ? sm * 0.5 : r;                                      // zeroflg = True for wet & dry
+  r = zero ? (ZEROFLG ? sm * 0.5 : 0.0) : r;                   // zeroflg = True for wet & dry, False for liquid & ice
   r = same ? x1 : r;
   r = negative ? 0.0 : r;
   return r;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Opt-in physics the reference leaves at pyrtlib's defaults: cloud liquid / ice
+// absorption (cloudy=True + init_cloudy) and spherical refracted ray tracing (ray_tracing=True).
+// Only the OPT instantiations of the fused kernel contain this code; the clear-sky kernel is untouched.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ cplx clog_(cplx w) {       // principal complex logarithm
+  return {0.5 * flog(__builtin_fma(w.re, w.re, w.im * w.im)), atan2(w.im, w.re)};
+}
+
+// RTEquation.cloudy_absorption + LiqAbsModel.liquid_water_absorption [EXT]: Np/km per level for NFC frequencies.
+// denl / deni in g m-3.  Skipped (all zeros) when no lane of the wave holds any cloud.
+template <int NFC>
+__device__ __forceinline__ void cloud_absorb(cmodel M, double tk, double denl, double deni, const double* sfq,
+                                             double (&aliq)[NFC], double (&aice)[NFC]) {
+#pragma unroll
+  for (int j = 0; j < NFC; ++j) { aliq[j] = 0.0; aice[j] = 0.0; }
+  const bool liq = denl > 0.0, ice = deni > 0.0;
+  if (!__any(liq || ice)) return;
+  // ice: (8.18645 / wavelength[cm]) * deni * 0.000959553 dB/km -> Np/km
+  const double kice = 8.18645 * 0.000959553 * (0.1 * 2.302585092994045684) / 29.9792458;
+  if (M->liq_mode == 0) {
+    // Liebe, Hufford & Manabe 1991 / MPM93 double Debye
+    const double theta1 = 1.0 - fdiv(300.0, tk);
+    const double eps0 = 77.66 - 103.3 * theta1;
+    const double eps1 = 0.0671 * eps0;
+    const double eps2 = 3.52;
+    const double fp = (316.0 * theta1 + 146.4) * theta1 + 20.2;
+    const double fs = 39.8 * fp;
+    const double rfp = fdiv(1.0, fp), rfs = fdiv(1.0, fs);
+#pragma unroll
+    for (int j = 0; j < NFC; ++j) {
+      const double f = sfq[2 * j];
+      const cplx t1 = cdiv(cplx{eps0 - eps1, 0.0}, cplx{1.0, f * rfp});
+      const cplx t2 = cdiv(cplx{eps1 - eps2, 0.0}, cplx{1.0, f * rfs});
+      const cplx eps = {t1.re + t2.re + eps2, t1.im + t2.im};
+      const cplx re = cdiv(cplx{eps.re - 1.0, eps.im}, cplx{eps.re + 2.0, eps.im});
+      aliq[j] = liq ? -0.06286 * re.im * f * denl : 0.0;
+      aice[j] = ice ? kice * f * deni : 0.0;
+    }
+  } else {
+    // Rosenkranz 2015: Patek 2009 static constant, Ellison 2007 Debye term, B-band term
+    const double tc = tk - 273.15;
+    const double lth = flog(fdiv(300.0, tk));
+    const double eps0 = -43.7527 * fexp(0.05 * lth) + 299.504 * fexp(1.47 * lth) - 399.364 * fexp(2.11 * lth) +
+                        221.327 * fexp(2.31 * lth);
+    const double delta = 80.69715 * fexp(-tc * (1.0 / 226.45));
+    const double sd = 1164.023 * fexp(fdiv(-651.4728, tc + 133.07));
+    const double deltab = 4.008724 * fexp(-tc * (1.0 / 103.05));
+    const double hdelta = 0.5 * deltab;
+    const double f1 = 10.46012 + tc * (0.1454962 + tc * (0.063267156 + tc * 0.00093786645));
+    const cplx z1 = {-0.75 * f1, f1};
+    const cplx z2 = {-4500.0, 2000.0};
+    const cplx cnorm = clog_(cdiv(z2, z1));
+    const cplx icnorm = crecip(cnorm);                       // 1/cnorm; 1/conj(cnorm) is its conjugate
+#pragma unroll
+    for (int j = 0; j < NFC; ++j) {
+      const double f = sfq[2 * j];
+      const cplx z = {0.0, f};
+      const cplx kap0 = cdiv(cplx{0.0, -delta * f}, cplx{sd, f});              // -delta z / (sd + z)
+      const cplx lp = clog_(cdiv(cplx{z.re - z2.re, z.im - z2.im}, cplx{z.re - z1.re, z.im - z1.im}));
+      const cplx lj = clog_(cdiv(cplx{z.re - z2.re, z.im + z2.im}, cplx{z.re - z1.re, z.im + z1.im}));
+      const cplx chip = cmul(cplx{hdelta * lp.re, hdelta * lp.im}, icnorm);
+      const cplx chij = cmul(cplx{hdelta * lj.re, hdelta * lj.im}, cplx{icnorm.re, -icnorm.im});
+      const cplx eps = {eps0 + (kap0.re + (chip.re + chij.re - deltab)), kap0.im + (chip.im + chij.im)};
+      const cplx re = cdiv(cplx{eps.re - 1.0, eps.im}, cplx{eps.re + 2.0, eps.im});
+      aliq[j] = liq ? -0.06286 * re.im * f * denl : 0.0;
+      aice[j] = ice ? kice * f * deni : 0.0;
+    }
+  }
+}
+
+// RTEquation.refractivity [EXT] (Thayer 1974): refractive index at one level
+__device__ __forceinline__ double thayer_refindex(double p, double tk, double e) {
+  const double pa = p - e, tc = tk - 273.16, tk2 = tk * tk, tc2 = tc * tc;
+  const double rza = 1.0 + pa * (5.79e-07 * (1.0 + 0.52 / tk) - (0.00094611 * tc) / tk2);
+  const double rzw = 1.0 + 1650.0 * (e / (tk * tk2)) * (1.0 - 0.01317 * tc + 0.000175 * tc2 + 1.44e-06 * (tc2 * tc));
+  const double wetn = (64.79 * (e / tk) + 377600.0 * (e / tk2)) * rzw;
+  const double dryn = 77.6036 * (pa / tk) * rza;
+  return 1.0 + (dryn + wetn) * 1e-06;
+}
+
+// RTEquation.ray_tracing [EXT] (TBMODEL RAYTRAC: Dutton, Thayer & Westwater after Bean & Dutton fig. 3.20).
+// One thread per (profile, angle) walks the levels in the reference's own order and stores the PATH FACTOR
+// ds_i / dz_i per layer, amf [nprof][nang][nlev] (entry 0 = 0): the slant-path integration multiplies the
+// zenith layer optical depth by it, exactly where the plane-parallel path multiplies by 1/sin(elev).
+// A trapped ray (ducting) gives NaN factors for that angle and duct[profile] = 1.  Ordinary libm calls: this
+// pre-kernel is ~0.1 % of the arithmetic of the opt-in path and is not tuned.
+constexpr double EARTH_RADIUS_KM = 6370.949;
+__global__ void __launch_bounds__(64)
+k_ray_paths(const double* __restrict__ z, const double* __restrict__ p, const double* __restrict__ t,
+            const double* __restrict__ rh, int64_t nprof, int nlev, const double* __restrict__ elev_deg, int nang,
+            double* __restrict__ amf, uint8_t* __restrict__ duct) {
+  const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= nprof * nang) return;
+  const int64_t prof = g / nang;
+  const int a = (int)(g - prof * nang);
+  const double* zp = z + prof * nlev; const double* pp = p + prof * nlev;
+  const double* tp = t + prof * nlev; const double* rp = rh + prof * nlev;
+  double* out = amf + g * nlev;
+  const double angle = elev_deg[a];
+  const double qnan = __builtin_nan("");
+  out[0] = 0.0;
+  bool bad = isnan(angle);
+  for (int i = 0; i < nlev; ++i) bad = bad || isnan(zp[i]) || isnan(pp[i]) || isnan(tp[i]) || isnan(rp[i]);
+  if (bad) { for (int i = 1; i < nlev; ++i) out[i] = qnan; return; }   // NaN inputs are the main kernel's business
+  if ((angle >= 89.0 && angle <= 91.0) || (angle >= -91.0 && angle <= -89.0)) {
+    for (int i = 1; i < nlev; ++i) out[i] = (zp[i] - zp[i - 1] != 0.0) ? 1.0 : 0.0;
+    return;
+  }
+  const double z0 = zp[0];
+  const double theta0 = angle * (M_PI / 180.0);
+  const double rs = EARTH_RADIUS_KM + 0.0 + z0;
+  const double costh0 = cos(theta0), sina = sin(theta0 * 0.5);
+  const double a0 = 2.0 * (sina * sina);
+  const double n0 = thayer_refindex(pp[0], tp[0], goff_gratch_e(tp[0], rp[0]));
+  double phil = 0.0, taul = 0.0, rl = rs, tanthl = tan(theta0), nprev = n0, zprev = 0.0;
+  bool trapped = false;
+  for (int i = 1; i < nlev; ++i) {
+    const double zi = zp[i] - z0;
+    const double ni = thayer_refindex(pp[i], tp[i], goff_gratch_e(tp[i], rp[i]));
+    double dsi = qnan;
+    if (!trapped) {
+      const double r = EARTH_RADIUS_KM + zi + z0;
+      double refbar;
+      if (ni == nprev || ni == 1.0 || nprev == 1.0) refbar = (ni + nprev) * 0.5;
+      else refbar = 1.0 + (nprev - ni) / (log((nprev - 1.0) / (ni - 1.0)));
+      const double argdth = zi / rs - ((n0 - ni) * costh0 / ni);
+      const double argth = 0.5 * (a0 + argdth) / r;
+      if (argth <= 0.0) {
+        trapped = true;
+      } else {
+        const double sint = sqrt(r * argth);
+        double theta = 2.0 * asin(sint), dtheta;
+        if ((theta - 2.0 * theta0) <= 0.0) {
+          const double dendth = 2.0 * (sint + sina) * cos((theta + theta0) * 0.25);
+          const double sind4 = (0.5 * argdth - zi * argth) / dendth;
+          dtheta = 4.0 * asin(sind4);
+          theta = theta0 + dtheta;
+        } else {
+          dtheta = theta - theta0;
+        }
+        const double tanth = tan(theta);
+        const double cthbar = ((1.0 / tanth) + (1.0 / tanthl)) * 0.5;
+        const double dtau = cthbar * (nprev - ni) / refbar;
+        const double tau = taul + dtau;
+        const double phi = dtheta + tau;
+        const double sh = sin((phi - phil) * 0.5);
+        dsi = sqrt((zi - zprev) * (zi - zprev) + 4.0 * r * rl * (sh * sh));
+        if (dtau != 0.0) {
+          const double dtaua = fabs(tau - taul);
+          dsi = dsi * (dtaua / (2.0 * sin(dtaua * 0.5)));
+        }
+        phil = phi; taul = tau; rl = r; tanthl = tanth;
+      }
+    }
+    const double dz = zi - zprev;
+    out[i] = trapped ? qnan : ((dz != 0.0) ? dsi / dz : 0.0);
+    nprev = ni; zprev = zi;
+  }
+  if (trapped) {
+    for (int i = 1; i < nlev; ++i) out[i] = qnan;       // pyrtlib gives up on the whole ray
+    duct[prof] = 1;
+  }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -807,6 +973,11 @@ struct FusedArgs {
   int nlev, nf, nang;
   int write_valid;         // 1: this launch has one workgroup per profile and sets valid = 1 itself
   LaunchGeom g;
+  // opt-in physics (read by the OPT instantiations only)
+  const double* denliq; const double* denice;   // [nprof][nlev] g m-3, either may be null
+  const double* amf;       // [nprof][nang][nlev] ray-traced path factor ds/dz, or null (plane-parallel)
+  const uint8_t* duct;     // [nprof] 1: a ray of this profile was trapped (valid = 3)
+  double* tauliq; double* tauice;               // optional [nprof][nang][nf]
 };
 
 // NaN / negative-absorption exit: every output of this (profile, chunk) becomes NaN
@@ -821,6 +992,8 @@ __device__ __forceinline__ void blank_outputs(const FusedArgs& A, int64_t prof, 
     if (A.tmr) A.tmr[o] = qnan;
     if (A.tauwet) A.tauwet[o] = qnan;
     if (A.taudry) A.taudry[o] = qnan;
+    if (A.tauliq) A.tauliq[o] = qnan;
+    if (A.tauice) A.tauice[o] = qnan;
   }
   if (A.taulay) for (int it = tid; it < nfc * nlev; it += nthreads)
     A.taulay[(prof * A.nf + jbase + it / nlev) * nlev + it % nlev] = qnan;
@@ -833,7 +1006,7 @@ __device__ __forceinline__ void blank_outputs(const FusedArgs& A, int64_t prof, 
 #ifndef MWRT_MIN_WAVES
 #define MWRT_MIN_WAVES 1
 #endif
-template <int NFC, int NFK, int MAXT>
+template <int NFC, int NFK, int MAXT, bool OPT = false>
 __global__ void __launch_bounds__(MAXT, (MAXT <= 256 ? MWRT_MIN_WAVES : 1))
 k_tb_fused(const FusedArgs A) {
   static_assert(NFC % NFK == 0, "NFC must be a multiple of NFK");
@@ -882,6 +1055,12 @@ k_tb_fused(const FusedArgs A) {
   const int64_t off = pin * nlev + (active ? tid : 0);
   const double zi = A.z[off], pi = A.p[off], ti = A.t[off], rhi = A.rh[off];
   if (active && (isnan(zi) || isnan(pi) || isnan(ti) || isnan(rhi))) atomicOr(&s_flag, 1);
+  double denl = 0.0, deni = 0.0;
+  if constexpr (OPT) {
+    if (A.denliq) denl = A.denliq[off];
+    if (A.denice) deni = A.denice[off];
+    if (active && (isnan(denl) || isnan(deni))) atomicOr(&s_flag, 1);
+  }
   __syncthreads();
   if (s_flag) {                               // check_for_nans: outputs stay NaN, valid = 0
     blank_outputs(A, prof, jbase, nfc, tid, nthreads);
@@ -920,6 +1099,34 @@ k_tb_fused(const FusedArgs A) {
       td[j] = has_prev ? layer_value(adry[j], pd, neg) * dz : 0.0;
     }
   }
+  // cloud liquid / ice (opt-in): same layer rule with zeroflg = False; tau = ((wet + dry) + ice) + liquid
+  double tl[OPT ? NFC : 1], tci[OPT ? NFC : 1];
+  if constexpr (OPT) {
+#pragma unroll
+    for (int j = 0; j < NFC; ++j) { tl[j] = 0.0; tci[j] = 0.0; }
+    if (A.denliq || A.denice) {
+      double aliq[NFC], aice[NFC];
+      cloud_absorb<NFC>(M, ti, denl, deni, sfq, aliq, aice);
+      __syncthreads();                          // the wet / dry seam rows have been read
+      if (lane == WAVE - 1) {
+#pragma unroll
+        for (int j = 0; j < NFC; ++j) { edge[wave * 2 * NFC + j] = aliq[j]; edge[wave * 2 * NFC + NFC + j] = aice[j]; }
+      }
+      __syncthreads();
+      const double z0 = A.z[pin * nlev];
+      const double dz = (active && tid > 0) ? ((zi - z0) - (A.z[off - 1] - z0)) : 0.0;
+      const bool seam = (lane == 0) && (wave > 0);
+      const bool has_prev = active && tid > 0;
+#pragma unroll
+      for (int j = 0; j < NFC; ++j) {
+        double pl = __shfl_up(aliq[j], 1, WAVE);
+        double pc = __shfl_up(aice[j], 1, WAVE);
+        if (seam) { pl = edge[(wave - 1) * 2 * NFC + j]; pc = edge[(wave - 1) * 2 * NFC + NFC + j]; }
+        tl[j] = has_prev ? layer_value<false>(aliq[j], pl, neg) * dz : 0.0;
+        tci[j] = has_prev ? layer_value<false>(aice[j], pc, neg) * dz : 0.0;
+      }
+    }
+  }
   if (neg) atomicOr(&s_flag, 2);
   __syncthreads();
   if (s_flag) {                               // pyrtlib raises ValueError here: flag 2, NaN out
@@ -931,9 +1138,14 @@ k_tb_fused(const FusedArgs A) {
   if (A.taulay && active) {
 #pragma unroll
     for (int j = 0; j < NFC; ++j)
-      if (j < nfc) A.taulay[(prof * A.nf + jbase + j) * nlev + tid] = tw[j] + td[j];
+      if (j < nfc) {
+        double tz = tw[j] + td[j];
+        if constexpr (OPT) tz = (tz + tci[j]) + tl[j];
+        A.taulay[(prof * A.nf + jbase + j) * nlev + tid] = tz;
+      }
   }
-  const bool want_tau = (A.tauwet != nullptr) || (A.taudry != nullptr);
+  bool want_tau = (A.tauwet != nullptr) || (A.taudry != nullptr);
+  if constexpr (OPT) want_tau = want_tau || (A.tauliq != nullptr) || (A.tauice != nullptr);
   const int nseg = A.g.nseg, seglen = A.g.seglen;
 
   // ---- phase K2: slant-path RTE (RTEquation.planck, from_sat = False [EXT]), NFK rows at a time ----
@@ -947,17 +1159,58 @@ k_tb_fused(const FusedArgs A) {
 #pragma unroll
       for (int jj = 0; jj < NFK; ++jj) {
         const int j = h * NFK + jj;
-        tau[jj * ld + tid] = tw[j] + td[j];
+        double tz = tw[j] + td[j];
+        if constexpr (OPT) tz = (tz + tci[j]) + tl[j];
+        tau[jj * ld + tid] = tz;
         bof[jj * ld + tid] = planck_b(sfq[2 * j] * hkt);
       }
     }
     // optional zenith opacity sums (tauwet / taudry columns); deterministic order
-    double swet[NFK], sdry[NFK];
-    if (want_tau) {
+    double swet[NFK], sdry[NFK], sliq[OPT ? NFK : 1], sice[OPT ? NFK : 1];
+    const bool rays = OPT && A.amf != nullptr;
+    if (want_tau && !rays) {
 #pragma unroll
       for (int jj = 0; jj < NFK; ++jj) {
         swet[jj] = block_sum(tw[h * NFK + jj], scratch, tid, nthreads);
         sdry[jj] = block_sum(td[h * NFK + jj], scratch, tid, nthreads);
+        if constexpr (OPT) {
+          sliq[jj] = block_sum(tl[h * NFK + jj], scratch, tid, nthreads);
+          sice[jj] = block_sum(tci[h * NFK + jj], scratch, tid, nthreads);
+        }
+      }
+    }
+    if constexpr (OPT) {
+      if (want_tau && rays) {
+        // ray-traced paths: the opacity columns are sums of layer value x path factor, one species at a
+        // time through the tau rows (the DataFrame path of a single execute(); not a throughput path)
+        const int npairs_r = nfk * nang;
+        for (int sp = 0; sp < 4; ++sp) {
+          double* outp = sp == 0 ? A.tauwet : sp == 1 ? A.taudry : sp == 2 ? A.tauliq : A.tauice;
+          __syncthreads();
+          if (active) {
+#pragma unroll
+            for (int jj = 0; jj < NFK; ++jj) {
+              const int j = h * NFK + jj;
+              tau[jj * ld + tid] = sp == 0 ? tw[j] : sp == 1 ? td[j] : sp == 2 ? tl[j] : tci[j];
+            }
+          }
+          __syncthreads();
+          if (outp) for (int pr = tid; pr < npairs_r; pr += nthreads) {
+            const int jj = pr / nang, a = pr - jj * nang;
+            const double* fr = A.amf + (pin * nang + a) * nlev;
+            double acc = 0.0;
+            for (int i = 1; i < nlev; ++i) acc += tau[jj * ld + i] * fr[i];
+            outp[(prof * nang + a) * A.nf + jbase + h * NFK + jj] = acc;
+          }
+        }
+        __syncthreads();
+        if (active) {
+#pragma unroll
+          for (int jj = 0; jj < NFK; ++jj) {
+            const int j = h * NFK + jj;
+            tau[jj * ld + tid] = ((tw[j] + td[j]) + tci[j]) + tl[j];
+          }
+        }
       }
     }
     __syncthreads();
@@ -974,10 +1227,12 @@ k_tb_fused(const FusedArgs A) {
       const int hi = min(lo + seglen, nlev);
       const double* tj = tau + jj * ld;
       const double* bj = bof + jj * ld;
+      const double* fr = nullptr;
+      if constexpr (OPT) fr = A.amf ? A.amf + (pin * nang + a) * nlev : nullptr;
       double T = 1.0, B = 0.0, S = 0.0;
       double bprev = (lo < nlev) ? bj[lo - 1] : 0.0;
       for (int i = lo; i < hi; ++i) {
-        const double tl = tj[i] * am;
+        const double tl = tj[i] * ((OPT && fr) ? fr[i] : am);
         const double E = __all(fabs(tl) <= EXP_SMALL_X) ? fexp_small(-tl) : fexp(-tl);
         const double bi = bj[i];
         const double lay = fdiv1(__builtin_fma(bi, E, bprev), 1.0 + E);
@@ -1014,15 +1269,26 @@ k_tb_fused(const FusedArgs A) {
       A.tb[o] = fdiv(hvk, flog(1.0 + fdiv(1.0, boftotl)));
       if (A.tbatm) A.tbatm[o] = fdiv(hvk, flog(1.0 + fdiv(1.0, B)));
       if (A.tmr) A.tmr[o] = fdiv(hvk, flog(1.0 + fdiv(1.0, boftmr)));
-      if (want_tau) {
+      if (want_tau && !rays) {
         const double am = cam[a];
-        double sw = 0.0, sd = 0.0;
+        double sw = 0.0, sd = 0.0, sl = 0.0, si = 0.0;
 #pragma unroll
-        for (int q2 = 0; q2 < NFK; ++q2) if (q2 == jj) { sw = swet[q2]; sd = sdry[q2]; }
+        for (int q2 = 0; q2 < NFK; ++q2) if (q2 == jj) {
+          sw = swet[q2]; sd = sdry[q2];
+          if constexpr (OPT) { sl = sliq[q2]; si = sice[q2]; }
+        }
         if (A.tauwet) A.tauwet[o] = sw * am;
         if (A.taudry) A.taudry[o] = sd * am;
+        if constexpr (OPT) {
+          if (A.tauliq) A.tauliq[o] = sl * am;
+          if (A.tauice) A.tauice[o] = si * am;
+        }
       }
     }
+  }
+  if constexpr (OPT) {
+    // a trapped ray (ducting) leaves its angle NaN and marks the profile 3
+    if (A.duct && A.duct[pin]) { if (tid == 0) A.valid[prof] = 3; return; }
   }
   if (A.write_valid && tid == 0) A.valid[prof] = 1;
 }

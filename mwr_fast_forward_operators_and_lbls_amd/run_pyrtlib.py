@@ -7,8 +7,10 @@ Mirror of python_src/old_run_pyrtlib/run_pyrtlib_on_all.py: same flags (-i dir, 
 script that is not in the repository (:36); here each file is processed in-process by the HIP
 operator.  Output contract = what the legacy merger reads
 (merge_data_into_netCDF/old_merge2nc.py:361-362, :417-435): ``<file>_out.txt``, a CSV with a
-``tbtotal`` column of 252 rows = [cropped, uncropped] x 9 models x 14 channels (zenith); models
-this build has no tables for (R03, R16, R19, R19SD) are written as NaN rows.
+``tbtotal`` column of 252 rows = [cropped, uncropped] x 9 models x 14 channels (zenith).  All nine names
+have tables; R03, R16, R19, R19SD and R24 are served by the nearest restated family (spectroscopy.py,
+``alias_of``: one warning per name, provenance in ``ModelTables.provenance``).  A name with no tables at all
+would be written as NaN rows.
 
 Input files: ``.npz`` holding z [km], p [hPa], t [K], rh [0-1] ground -> top (and optional
 ``*_crop`` variants); raw radiosonde NetCDF parsing is pre-processing and out of scope.

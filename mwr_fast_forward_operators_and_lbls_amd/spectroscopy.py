@@ -92,6 +92,8 @@ class ModelTables:
     n2_n: float
     n2_fdep: int             # frequency-dependence factor on/off
     n2_ptot: int             # 1: uses total pressure (old models, folded into the O2 routine); 0: dry pressure
+    # ---- cloud liquid (LiqAbsModel; only read when the caller opts into cloudy=True) ----
+    liq_mode: int = 1        # 0: Liebe 1991 / MPM93 double Debye (R98, R03, R16, R17); 1: Rosenkranz 2015 (R19+)
     # ---- RTE constants ----
     t_cosmic: float = 2.736
     planck_h: float = 6.6260755e-34
@@ -143,7 +145,7 @@ class ModelTables:
                   "h2o_pvap_div", "h2o_den_coef", "h2o_shift_mode",
                   "o2_x", "o2_wb300", "o2_pvap_div", "o2_wv_factor", "o2_nonres", "o2_coef",
                   "o2_mix_mode", "o2_line1_dens",
-                  "n2_l", "n2_m", "n2_n", "n2_fdep", "n2_ptot",
+                  "n2_l", "n2_m", "n2_n", "n2_fdep", "n2_ptot", "liq_mode",
                   "t_cosmic", "planck_h", "boltzmann_k"):
             setattr(c, k, getattr(self, k))
         for k in self.H2O_KEYS:
@@ -163,7 +165,7 @@ class MwrtModelDesc(ctypes.Structure):
         [("n_h2o", ctypes.c_int32), ("n_o2", ctypes.c_int32),
          ("h2o_shift_mode", ctypes.c_int32), ("o2_mix_mode", ctypes.c_int32),
          ("o2_line1_dens", ctypes.c_int32), ("n2_fdep", ctypes.c_int32),
-         ("n2_ptot", ctypes.c_int32), ("reserved0", ctypes.c_int32)]
+         ("n2_ptot", ctypes.c_int32), ("liq_mode", ctypes.c_int32)]
         + [(k, ctypes.c_double) for k in (
             "h2o_reftcon", "h2o_reftline", "h2o_cf", "h2o_xcf", "h2o_cs", "h2o_xcs",
             "h2o_pvap_div", "h2o_den_coef",
@@ -438,7 +440,7 @@ _register(ModelTables(
     h2o_pvap_div=217.0, h2o_den_coef=3.335e16, h2o_shift_mode=SHIFT_NONE, h2o=_copy(_H2O_R98),
     o2_x=0.8, o2_wb300=0.56, o2_pvap_div=217.0, o2_wv_factor=1.1, o2_nonres=1.6e-17,
     o2_coef=0.5034e12 / _PI_R98, o2_mix_mode=MIX_FIRST_ORDER_PTOT, o2_line1_dens=1, o2=_copy(_O2_R98),
-    n2_l=6.4e-14, n2_m=3.55, n2_n=1.0, n2_fdep=0, n2_ptot=1,
+    n2_l=6.4e-14, n2_m=3.55, n2_n=1.0, n2_fdep=0, n2_ptot=1, liq_mode=0,
 ))
 
 _register(ModelTables(
@@ -448,7 +450,7 @@ _register(ModelTables(
     h2o_pvap_div=217.0, h2o_den_coef=3.344e16, h2o_shift_mode=SHIFT_AIR_SELF, h2o=_copy(_H2O_R17),
     o2_x=0.8, o2_wb300=0.56, o2_pvap_div=217.0, o2_wv_factor=1.1, o2_nonres=1.584e-17,
     o2_coef=1.6097e11, o2_mix_mode=MIX_FIRST_ORDER_PTOT, o2_line1_dens=0, o2=_copy(_O2_R17),
-    n2_l=6.5e-14, n2_m=3.6, n2_n=1.29, n2_fdep=1, n2_ptot=1,
+    n2_l=6.5e-14, n2_m=3.6, n2_n=1.29, n2_fdep=1, n2_ptot=1, liq_mode=0,
 ))
 
 _register(ModelTables(
@@ -471,6 +473,31 @@ _register(dataclasses.replace(
     _MODELS["R20SD"], name="R24", alias_of="R20SD",
     provenance="carried as the R20SD parameter family: the 2021-2024 revisions in pyrtlib's R24 could not "
                "be restated offline -- UNPINNED, replace via tools/export_pyrtlib_tables.py",
+    h2o=_copy(_H2O_SD), o2=_copy(_O2_R20)))
+
+# The remaining names of the reference's list (PyRTlib_processing.py:90; the legacy runner writes one CSV
+# row block per name, merge_data_into_netCDF/old_merge2nc.py:417-435).  Their own digit sets could not be
+# restated offline; each is SERVED BY THE NEAREST FAMILY above and says so (alias_of -> one-time warning,
+# provenance in every output): confidence is that of the family, minus whatever the release changed.
+_register(dataclasses.replace(
+    _MODELS["R98"], name="R03", alias_of="R98",
+    provenance="Rosenkranz 2003 release carried as the R98 tables (its 22-GHz width / continuum updates are NOT in "
+               "here) -- UNPINNED, replace via tools/export_pyrtlib_tables.py",
+    h2o=_copy(_H2O_R98), o2=_copy(_O2_R98)))
+_register(dataclasses.replace(
+    _MODELS["R17"], name="R16", alias_of="R17",
+    provenance="Rosenkranz 2016 release carried as the R17 tables (R17's own revisions are NOT undone) -- "
+               "UNPINNED, replace via tools/export_pyrtlib_tables.py",
+    h2o=_copy(_H2O_R17), o2=_copy(_O2_R17)))
+_register(dataclasses.replace(
+    _MODELS["R20"], name="R19", alias_of="R20",
+    provenance="Rosenkranz 2019 release carried as the R20 tables (second-order O2 mixing family, no speed "
+               "dependence) -- UNPINNED, replace via tools/export_pyrtlib_tables.py",
+    h2o=_no_sd(_H2O_SD), o2=_copy(_O2_R20)))
+_register(dataclasses.replace(
+    _MODELS["R20SD"], name="R19SD", alias_of="R20SD",
+    provenance="Rosenkranz 2019 speed-dependent release carried as the R20SD tables -- UNPINNED, replace via "
+               "tools/export_pyrtlib_tables.py",
     h2o=_copy(_H2O_SD), o2=_copy(_O2_R20)))
 
 #: model names in the order the reference wrapper lists them (PyRTlib_processing.py:90)

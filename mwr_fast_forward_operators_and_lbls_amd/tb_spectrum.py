@@ -15,8 +15,10 @@ Same constructor argument meaning (z km ascending, p hPa, T K, rh fraction, frq 
 angles in degrees), same ``init_absmdl`` names, same DataFrame columns and row order
 (angle-major, frequency-minor) as pyrtlib [EXT].
 
-Scope: clear sky, plane-parallel, ground-based (downwelling).  Everything
-pyrtlib offers beyond that raises ``NotImplementedError`` -- never a silent approximation.
+Scope: ground-based (downwelling); clear sky and plane-parallel by default like the
+reference's calls.  Opt-in, as in pyrtlib: ``cloudy=True`` + ``init_cloudy(cldh, denice, denliq)`` (cloud
+liquid / ice absorption) and ``ray_tracing=True`` (spherical refracted slant paths).  What is still
+outside (upwelling, ozone, amu perturbation) raises ``NotImplementedError`` -- never a silent approximation.
 pyrtlib keeps the model in process-global class state (why the reference re-issues
 ``init_absmdl`` before every ``execute``, :124,:132,:140,:148); here it is per instance.
 """
@@ -56,6 +58,9 @@ class TbCloudRTE(object):
         self.cloudy = cloudy
         self._absmdl = absmdl
         self._tables = None
+        self.cldh = None
+        self.denliq = None
+        self.denice = None
         if absmdl:
             self.init_absmdl(absmdl)
 
@@ -79,8 +84,17 @@ class TbCloudRTE(object):
         raise NotImplementedError("spectroscopic-uncertainty perturbation (amu) is outside the hot path")
 
     def init_cloudy(self, cldh, denice, denliq) -> None:
-        raise NotImplementedError("cloudy RTE is outside the hot path (the reference runs clear sky, "
-                                  "old_processing.py:558-563)")
+        """pyrtlib's signature: cloud base / top heights ``cldh`` (2, ncld) [km], ice and liquid density
+        profiles [g m-3] on the instance's levels.  Only read when ``cloudy`` is True (opt-in: the reference
+        runs clear sky, old_processing.py:558-563).  ``cldh`` only feeds pyrtlib's cloud radiating temperature
+        (``tmrcld``), which is not evaluated here (the column stays 0)."""
+        denice = np.asarray(denice, dtype=np.float64)
+        denliq = np.asarray(denliq, dtype=np.float64)
+        if denice.shape != self.z.shape or denliq.shape != self.z.shape:
+            raise ValueError("denice and denliq must have one value per level")
+        self.cldh = np.asarray(cldh, dtype=np.float64)
+        self.denice = denice
+        self.denliq = denliq
 
     # -- the hot path -----------------------------------------------------------------------------
     def execute(self, only_bt: Optional[bool] = True):
@@ -92,26 +106,35 @@ class TbCloudRTE(object):
         if self._satellite:
             raise NotImplementedError("upwelling (satellite=True) is outside the hot path; the reference "
                                       "sets rte.satellite = False (PyRTlib_processing.py:125)")
-        if self.cloudy:
-            raise NotImplementedError("cloudy=True is outside the hot path")
-        if self.ray_tracing:
-            raise NotImplementedError("ray_tracing=True is outside the hot path (plane-parallel only)")
         if self.o3n is not None:
-            raise NotImplementedError("ozone profile (o3n) is outside the hot path")
+            raise NotImplementedError("ozone profile (o3n) is outside the hot path: the O3 line list could not be "
+                                      "restated offline")
+        denliq = denice = None
+        if self.cloudy:
+            if self.denliq is None:
+                raise AttributeError("Set cloudy to True before running init_cloudy()")     # pyrtlib's wording
+            denliq, denice = self.denliq[None, :], self.denice[None, :]
 
         z, p, t, rh = (np.ascontiguousarray(a, dtype=np.float64)[None, :] for a in (self.z, self.p, self.tk, self.rh))
-        tb, valid, ex = _native.default_context().tb_batch(self._tables, z, p, t, rh, self.frq, self.angles, extras=True)
+        tb, valid, ex = _native.default_context().tb_batch(self._tables, z, p, t, rh, self.frq, self.angles, extras=True,
+                                                           denliq=denliq, denice=denice,
+                                                           ray_tracing=bool(self.ray_tracing))
         if valid[0] == 2:
             # pyrtlib raises inside RTEquation.exponential_integration on negative absorption
             raise ValueError("Error encountered in exponential_integration")
+        if valid[0] == 3:
+            raise ValueError("RayTrac_xxx: Ducting")
         n = self.nang * self.nf
         zeros = np.zeros(n)
         df = pd.DataFrame({'tbtotal': tb[0].reshape(n), 'tbatm': ex["tbatm"][0].reshape(n),
                            'tmr': ex["tmr"][0].reshape(n), 'tmrcld': zeros,
                            'tauwet': ex["tauwet"][0].reshape(n), 'taudry': ex["taudry"][0].reshape(n),
-                           'tauliq': zeros.copy(), 'tauice': zeros.copy()})
+                           'tauliq': ex["tauliq"][0].reshape(n), 'tauice': ex["tauice"][0].reshape(n)})
         if only_bt:
             return df
+        if self.ray_tracing:
+            raise NotImplementedError("per-angle layer optical depths are not returned with ray_tracing=True "
+                                      "(use only_bt=True)")
         # per-angle layer optical depths, shaped like pyrtlib's (nf, nang, nl) arrays
         amass = 1.0 / np.sin(self.angles * np.pi / 180)
         taulay = ex["taulay"][0][:, None, :] * amass[None, :, None]

@@ -13,7 +13,9 @@
  * doubles as the honest single-core CPU baseline ("port").
  *
  * Routines follow pyrtlib [EXT]: RTEquation.vapor, clearsky_absorption, H2OAbsModel.h2o_absorption,
- * O2AbsModel.o2_absorption, N2AbsModel.n2_absorption, exponential_integration, planck, bright.
+ * O2AbsModel.o2_absorption, N2AbsModel.n2_absorption, exponential_integration, planck, bright; and, for
+ * the opt-in physics, LiqAbsModel.liquid_water_absorption, RTEquation.cloudy_absorption,
+ * refractivity, ray_tracing.
  */
 #define _GNU_SOURCE
 #include <complex.h>
@@ -28,7 +30,7 @@
 /* Same field order as the product's mwrt_model_desc so a test can hand over the same bytes;
  * declared independently on purpose (oracle/ includes nothing from the product). */
 typedef struct lbl_tables {
-  int32_t n_h2o, n_o2, h2o_shift_mode, o2_mix_mode, o2_line1_dens, n2_fdep, n2_ptot, reserved0;
+  int32_t n_h2o, n_o2, h2o_shift_mode, o2_mix_mode, o2_line1_dens, n2_fdep, n2_ptot, liq_mode;
   double h2o_reftcon, h2o_reftline, h2o_cf, h2o_xcf, h2o_cs, h2o_xcs, h2o_pvap_div, h2o_den_coef;
   double o2_x, o2_wb300, o2_pvap_div, o2_wv_factor, o2_nonres, o2_coef;
   double n2_l, n2_m, n2_n;
@@ -220,43 +222,177 @@ static int expint(int zeroflg, const double* x, const double* ds, int nl, double
   return 0;
 }
 
+/* LiqAbsModel.liquid_water_absorption [EXT] (Rosenkranz ABLIQ), Np/km; liq_mode as in lbl_oracle.py */
+static double abliq(const lbl_tables* m, double water, double freq, double temp) {
+  if (water <= 0.0) return 0.0;
+  double complex eps;
+  if (m->liq_mode == 0) {
+    double theta1 = 1.0 - 300.0 / temp;
+    double eps0 = 77.66 - 103.3 * theta1;
+    double eps1 = 0.0671 * eps0;
+    double eps2 = 3.52;
+    double fp = (316.0 * theta1 + 146.4) * theta1 + 20.2;
+    double fs = 39.8 * fp;
+    eps = (eps0 - eps1) / (1.0 + I * (freq / fp)) + (eps1 - eps2) / (1.0 + I * (freq / fs)) + eps2;
+  } else {
+    double tc = temp - 273.15;
+    double complex z = I * freq;
+    double theta = 300.0 / temp;
+    double eps0 = -43.7527 * pow(theta, 0.05) + 299.504 * pow(theta, 1.47) - 399.364 * pow(theta, 2.11) +
+                  221.327 * pow(theta, 2.31);
+    double delta = 80.69715 * exp(-tc / 226.45);
+    double sd = 1164.023 * exp(-651.4728 / (tc + 133.07));
+    double complex kappa = -delta * z / (sd + z);
+    delta = 4.008724 * exp(-tc / 103.05);
+    double hdelta = delta / 2.0;
+    double f1 = 10.46012 + 0.1454962 * tc + 0.063267156 * tc * tc + 0.00093786645 * tc * tc * tc;
+    double complex z1 = (-0.75 + I * 1.0) * f1;
+    double complex z2 = -4500.0 + I * 2000.0;
+    double complex cnorm = clog(z2 / z1);
+    double complex chip = (hdelta * clog((z - z2) / (z - z1))) / cnorm;
+    double complex chij = (hdelta * clog((z - conj(z2)) / (z - conj(z1)))) / conj(cnorm);
+    double complex dchi = chip + chij - delta;
+    eps = eps0 + (kappa + dchi);
+  }
+  double complex re = (eps - 1.0) / (eps + 2.0);
+  return -0.06286 * cimag(re) * freq * water;
+}
+
+/* RTEquation.refractivity [EXT] (Thayer 1974): refractive index */
+static double refindex(double p, double tk, double e) {
+  double pa = p - e, tc = tk - 273.16, tk2 = tk * tk, tc2 = tc * tc;
+  double rza = 1.0 + pa * (5.79e-07 * (1.0 + 0.52 / tk) - (0.00094611 * tc) / tk2);
+  double rzw = 1.0 + 1650.0 * (e / (tk * tk2)) * (1.0 - 0.01317 * tc + 0.000175 * tc2 + 1.44e-06 * (tc2 * tc));
+  double wetn = (64.79 * (e / tk) + 377600.0 * (e / tk2)) * rzw;
+  double dryn = 77.6036 * (pa / tk) * rza;
+  return 1.0 + (dryn + wetn) * 1e-06;
+}
+
+/* RTEquation.ray_tracing [EXT] (TBMODEL RAYTRAC); returns -1 when the ray is trapped (ducting) */
+static int raytrace(int nl, const double* z, const double* n, double angle, double z0, double* ds) {
+  const double re = 6370.949;
+  ds[0] = 0.0;
+  if ((angle >= 89 && angle <= 91) || (angle >= -91 && angle <= -89)) {
+    for (int i = 1; i < nl; ++i) ds[i] = z[i] - z[i - 1];
+    return 0;
+  }
+  double theta0 = angle * (M_PI / 180.0);
+  double rs = re + z[0] + z0;
+  double costh0 = cos(theta0), sina = sin(theta0 * 0.5);
+  double a0 = 2.0 * (sina * sina);
+  double phil = 0.0, taul = 0.0, rl = re + z[0] + z0, tanthl = tan(theta0);
+  for (int i = 1; i < nl; ++i) {
+    double r = re + z[i] + z0, refbar;
+    if (n[i] == n[i - 1] || n[i] == 1.0 || n[i - 1] == 1.0) refbar = (n[i] + n[i - 1]) * 0.5;
+    else refbar = 1.0 + (n[i - 1] - n[i]) / (log((n[i - 1] - 1.0) / (n[i] - 1.0)));
+    double argdth = z[i] / rs - ((n[0] - n[i]) * costh0 / n[i]);
+    double argth = 0.5 * (a0 + argdth) / r;
+    if (argth <= 0) return -1;
+    double sint = sqrt(r * argth);
+    double theta = 2.0 * asin(sint), dtheta;
+    if ((theta - 2.0 * theta0) <= 0.0) {
+      double dendth = 2.0 * (sint + sina) * cos((theta + theta0) * 0.25);
+      double sind4 = (0.5 * argdth - z[i] * argth) / dendth;
+      dtheta = 4.0 * asin(sind4);
+      theta = theta0 + dtheta;
+    } else {
+      dtheta = theta - theta0;
+    }
+    double tanth = tan(theta);
+    double cthbar = ((1.0 / tanth) + (1.0 / tanthl)) * 0.5;
+    double dtau = cthbar * (n[i - 1] - n[i]) / refbar;
+    double tau = taul + dtau;
+    double phi = dtheta + tau;
+    double sh = sin((phi - phil) * 0.5);
+    ds[i] = sqrt((z[i] - z[i - 1]) * (z[i] - z[i - 1]) + 4.0 * r * rl * (sh * sh));
+    if (dtau != 0.0) {
+      double dtaua = fabs(tau - taul);
+      ds[i] = ds[i] * (dtaua / (2.0 * sin(dtaua * 0.5)));
+    }
+    phil = phi; taul = tau; rl = r; tanthl = tanth;
+  }
+  return 0;
+}
+
 /*
  * TbCloudRTE(z,p,t,rh,frq,angles) + init_absmdl + satellite=False + execute() for ONE profile
  * (PyRTlib_processing.py:123-126).  Outputs [nang][nf] each (pyrtlib DataFrame row order).
- * Returns 0 ok, 1 NaN input (outputs NaN), 2 negative absorption (pyrtlib raises ValueError).
+ * Opt-in physics: denliq / denice [g m-3 per level, NULL = clear sky] (cloudy=True + init_cloudy),
+ * ray_tracing != 0 (ray_tracing=True).
+ * Returns 0 ok, 1 NaN input (outputs NaN), 2 negative absorption (pyrtlib raises ValueError), 3 ducting.
+ * A NaN elevation blanks its own rows only (the wrapper's per-k check, :106, :117).
  */
-int lbl_tb_profile(const lbl_tables* m, int nl, const double* z, const double* p, const double* tk, const double* rh,
-                   int nf, const double* frq, int nang, const double* ang,
-                   double* tbtotal, double* tbatm, double* tmr, double* tauwet, double* taudry) {
+int lbl_tb_profile_opt(const lbl_tables* m, int nl, const double* z, const double* p, const double* tk, const double* rh,
+                       int nf, const double* frq, int nang, const double* ang,
+                       const double* denliq, const double* denice, int ray_tracing,
+                       double* tbtotal, double* tbatm, double* tmr, double* tauwet, double* taudry,
+                       double* tauliq, double* tauice) {
   const int nout = nf * nang;
-  int bad = 0;
+  int bad = 0, allnan = 1;
   for (int i = 0; i < nl; ++i) bad |= isnan(z[i]) || isnan(p[i]) || isnan(tk[i]) || isnan(rh[i]);
+  if (denliq) for (int i = 0; i < nl; ++i) bad |= isnan(denliq[i]);
+  if (denice) for (int i = 0; i < nl; ++i) bad |= isnan(denice[i]);
   for (int j = 0; j < nf; ++j) bad |= isnan(frq[j]);
-  for (int k = 0; k < nang; ++k) bad |= isnan(ang[k]);
-  if (bad) {
+  for (int k = 0; k < nang; ++k) allnan &= isnan(ang[k]);
+  if (bad || allnan) {
     fill_nan(nout, tbtotal, tbatm, tmr, tauwet, taudry);
+    if (tauliq) for (int o = 0; o < nout; ++o) tauliq[o] = NAN;
+    if (tauice) for (int o = 0; o < nout; ++o) tauice[o] = NAN;
     return 1;
   }
-  double* buf = (double*)malloc(sizeof(double) * (size_t)nl * 9);
+  const int cloudy = denliq != NULL || denice != NULL;
+  double* buf = (double*)malloc(sizeof(double) * (size_t)nl * 14);
   double *e = buf, *zz = buf + nl, *ds = buf + 2 * nl, *awet = buf + 3 * nl, *adry = buf + 4 * nl,
-         *pw = buf + 5 * nl, *pd = buf + 6 * nl, *boft = buf + 7 * nl, *tauprof = buf + 8 * nl;
-  for (int i = 0; i < nl; ++i) { e[i] = vapor_e(tk[i], rh[i]); zz[i] = z[i] - z[0]; }
+         *pw = buf + 5 * nl, *pd = buf + 6 * nl, *boft = buf + 7 * nl, *tauprof = buf + 8 * nl,
+         *aliq = buf + 9 * nl, *aice = buf + 10 * nl, *pl = buf + 11 * nl, *pi = buf + 12 * nl, *nref = buf + 13 * nl;
+  for (int i = 0; i < nl; ++i) {
+    e[i] = vapor_e(tk[i], rh[i]); zz[i] = z[i] - z[0]; nref[i] = refindex(p[i], tk[i], e[i]);
+    pl[i] = 0.0; pi[i] = 0.0;
+  }
   int rc = 0;
   for (int k = 0; k < nang && rc == 0; ++k) {
-    double amass = 1.0 / sin(ang[k] * M_PI / 180.0);
-    ds[0] = 0.0;
-    for (int i = 1; i < nl; ++i) ds[i] = (zz[i] - zz[i - 1]) * amass;
+    if (isnan(ang[k])) {
+      for (int j = 0; j < nf; ++j) {
+        const int o = k * nf + j;
+        tbtotal[o] = NAN;
+        if (tbatm) tbatm[o] = NAN;
+        if (tmr) tmr[o] = NAN;
+        if (tauwet) tauwet[o] = NAN;
+        if (taudry) taudry[o] = NAN;
+        if (tauliq) tauliq[o] = NAN;
+        if (tauice) tauice[o] = NAN;
+      }
+      continue;
+    }
+    if (ray_tracing) {
+      if (raytrace(nl, zz, nref, ang[k], z[0], ds)) { rc = 3; break; }
+    } else {
+      double amass = 1.0 / sin(ang[k] * M_PI / 180.0);
+      ds[0] = 0.0;
+      for (int i = 1; i < nl; ++i) ds[i] = (zz[i] - zz[i - 1]) * amass;
+    }
     for (int j = 0; j < nf; ++j) {
       for (int i = 0; i < nl; ++i) clearsky_abs(m, p[i], tk[i], e[i], frq[j], &awet[i], &adry[i]);
-      double sw, sd;
+      double sw, sd, sl = 0.0, si = 0.0;
       if (expint(1, awet, ds, nl, pw, &sw) || expint(1, adry, ds, nl, pd, &sd)) { rc = 2; break; }
+      if (cloudy) {
+        /* RTEquation.cloudy_absorption [EXT] */
+        const double wave = (299792458.0 * 100.0) / (frq[j] * 1e9);
+        const double db2np = log(10.0) * 0.1;
+        for (int i = 0; i < nl; ++i) {
+          aliq[i] = (denliq && denliq[i] > 0) ? abliq(m, denliq[i], frq[j], tk[i]) : 0.0;
+          aice[i] = 0.0;
+          if (denice && denice[i] > 0) { aice[i] = (8.18645 / wave) * denice[i] * 0.000959553; aice[i] = aice[i] * db2np; }
+        }
+        if (expint(0, aliq, ds, nl, pl, &sl) || expint(0, aice, ds, nl, pi, &si)) { rc = 2; break; }
+      }
       /* RTEquation.planck [EXT], ground-based branch */
       double hvk = (frq[j] * 1e9) * m->planck_h / m->boltzmann_k;
       double boftatm = 0.0;
       tauprof[0] = 0.0;
       boft[0] = 1.0 / (exp(hvk / tk[0]) - 1.0);
       for (int i = 1; i < nl; ++i) {
-        double taulay = pw[i] + pd[i] + 0.0 + 0.0;
+        double taulay = pw[i] + pd[i] + pi[i] + pl[i];
         boft[i] = 1.0 / (exp(hvk / tk[i]) - 1.0);
         double boftlay = (boft[i - 1] + boft[i] * exp(-taulay)) / (1.0 + exp(-taulay));
         double batmlay = boftlay * exp(-tauprof[i - 1]) * (1.0 - exp(-taulay));
@@ -277,11 +413,24 @@ int lbl_tb_profile(const lbl_tables* m, int nl, const double* z, const double* p
       if (tmr) tmr[o] = hvk / log(1.0 + (1.0 / boftmr));
       if (tauwet) tauwet[o] = sw;
       if (taudry) taudry[o] = sd;
+      if (tauliq) tauliq[o] = sl;
+      if (tauice) tauice[o] = si;
     }
   }
   free(buf);
-  if (rc == 2) fill_nan(nout, tbtotal, tbatm, tmr, tauwet, taudry);
+  if (rc >= 2) {
+    fill_nan(nout, tbtotal, tbatm, tmr, tauwet, taudry);
+    if (tauliq) for (int o = 0; o < nout; ++o) tauliq[o] = NAN;
+    if (tauice) for (int o = 0; o < nout; ++o) tauice[o] = NAN;
+  }
   return rc;
+}
+
+int lbl_tb_profile(const lbl_tables* m, int nl, const double* z, const double* p, const double* tk, const double* rh,
+                   int nf, const double* frq, int nang, const double* ang,
+                   double* tbtotal, double* tbatm, double* tmr, double* tauwet, double* taudry) {
+  return lbl_tb_profile_opt(m, nl, z, p, tk, rh, nf, frq, nang, ang, NULL, NULL, 0, tbtotal, tbatm, tmr, tauwet, taudry,
+                            NULL, NULL);
 }
 
 /* Batch driver: profiles [nprof][nl]; tb [nprof][nang][nf]; OpenMP over profiles when built with it. */

@@ -226,6 +226,145 @@ def clearsky_absorption(m, p, tk, e, frq):
     return awet, adry
 
 
+def liquid_water_absorption(m, water, freq, temp):
+    """LiqAbsModel.liquid_water_absorption [EXT] (Rosenkranz ABLIQ): Np/km by suspended droplets.
+
+    water [g m-3], freq [GHz], temp [K], scalars.  ``m.liq_mode`` 0: Liebe, Hufford & Manabe 1991 /
+    MPM93 double Debye (pyrtlib: R98, R03, R16, R17); 1: Rosenkranz 2015 (IEEE TGRS 53(3), 1387-93:
+    Patek 2009 static constant, Ellison 2007 Debye term, B-band term) (pyrtlib: R19 and later).
+    Recalled, NOT digit-checked: parity unpinned like the line tables."""
+    if water <= 0:
+        return 0.0
+    if m.liq_mode == 0:
+        theta1 = 1.0 - 300.0 / temp
+        eps0 = 77.66 - 103.3 * theta1
+        eps1 = 0.0671 * eps0
+        eps2 = 3.52
+        fp = (316.0 * theta1 + 146.4) * theta1 + 20.2
+        fs = 39.8 * fp
+        eps = (eps0 - eps1) / complex(1.0, freq / fp) + (eps1 - eps2) / complex(1.0, freq / fs) + eps2
+    else:
+        tc = temp - 273.15
+        z = complex(0.0, freq)
+        theta = 300.0 / temp
+        eps0 = -43.7527 * theta ** 0.05 + 299.504 * theta ** 1.47 - 399.364 * theta ** 2.11 + 221.327 * theta ** 2.31
+        delta = 80.69715 * np.exp(-tc / 226.45)
+        sd = 1164.023 * np.exp(-651.4728 / (tc + 133.07))
+        kappa = -delta * z / (sd + z)
+        delta = 4.008724 * np.exp(-tc / 103.05)
+        hdelta = delta / 2.0
+        f1 = 10.46012 + 0.1454962 * tc + 0.063267156 * tc ** 2 + 0.00093786645 * tc ** 3
+        z1 = complex(-0.75, 1.0) * f1
+        z2 = complex(-4500.0, 2000.0)
+        cnorm = np.log(z2 / z1)
+        chip = (hdelta * np.log((z - z2) / (z - z1))) / cnorm
+        chij = (hdelta * np.log((z - np.conj(z2)) / (z - np.conj(z1)))) / np.conj(cnorm)
+        dchi = chip + chij - delta
+        kappa = kappa + dchi
+        eps = eps0 + kappa
+    re = (eps - 1.0) / (eps + 2.0)
+    return float(-0.06286 * np.imag(re) * freq * water)
+
+
+def cloudy_absorption(m, tk, denl, deni, frq):
+    """RTEquation.cloudy_absorption [EXT]: liquid and ice cloud absorption per level, Np/km.
+    tk [K], denl / deni [g m-3] per level, frq scalar [GHz]."""
+    nl = len(tk)
+    c = 299792458.0 * 100.0                     # cm/s
+    ghz2hz = 1e9
+    db2np = np.log(10.0) * 0.1
+    wave = c / (frq * ghz2hz)
+    aliq = np.zeros(nl)
+    aice = np.zeros(nl)
+    for i in range(nl):
+        if denl[i] > 0:
+            aliq[i] = liquid_water_absorption(m, denl[i], frq, tk[i])
+        if deni[i] > 0:
+            aice[i] = (8.18645 / wave) * deni[i] * 0.000959553
+            aice[i] = aice[i] * db2np
+    return aliq, aice
+
+
+def refractivity(p, tk, e):
+    """RTEquation.refractivity [EXT] (Thayer 1974): dry / wet refractivity and refractive index per level."""
+    p = np.asarray(p, dtype=np.float64)
+    tk = np.asarray(tk, dtype=np.float64)
+    e = np.asarray(e, dtype=np.float64)
+    pa = p - e
+    tc = tk - 273.16
+    tk2 = tk * tk
+    tc2 = tc * tc
+    rza = 1.0 + pa * (5.79e-07 * (1.0 + 0.52 / tk) - (0.00094611 * tc) / tk2)
+    rzw = 1.0 + 1650.0 * (e / (tk * tk2)) * (1.0 - 0.01317 * tc + 0.000175 * tc2 + 1.44e-06 * (tc2 * tc))
+    wetn = (64.79 * (e / tk) + 377600.0 * (e / tk2)) * rzw
+    dryn = 77.6036 * (pa / tk) * rza
+    refindx = 1.0 + (dryn + wetn) * 1e-06
+    return dryn, wetn, refindx
+
+
+EARTH_RADIUS_KM = 6370.949
+
+
+def ray_tracing(z, refindx, angle, z0):
+    """RTEquation.ray_tracing [EXT] (TBMODEL RAYTRAC; Dutton, Thayer & Westwater after Bean & Dutton fig. 3.20):
+    slant path length per layer [km] through a spherically stratified, refracting atmosphere.
+
+    z [km above the antenna], refindx per level, angle = ELEVATION [deg], z0 = antenna height [km msl].
+    Within 1 degree of zenith the layer thicknesses are returned, as in the Fortran."""
+    deg2rad = np.pi / 180
+    re = EARTH_RADIUS_KM
+    nl = len(z)
+    ds = np.zeros(nl)
+    for i in range(nl):
+        if refindx[i] == 0:
+            raise ValueError("RayTrac_xxx: Negative rafractive index")
+    if (89 <= angle <= 91) or (-91 <= angle <= -89):
+        ds[1:] = z[1:] - z[:-1]
+        return ds
+    theta0 = angle * deg2rad
+    rs = re + z[0] + z0
+    costh0 = np.cos(theta0)
+    sina = np.sin(theta0 * 0.5)
+    a0 = 2.0 * (sina ** 2)
+    phil = 0.0
+    taul = 0.0
+    rl = re + z[0] + z0
+    tanthl = np.tan(theta0)
+    for i in range(1, nl):
+        r = re + z[i] + z0
+        if refindx[i] == refindx[i - 1] or refindx[i] == 1.0 or refindx[i - 1] == 1.0:
+            refbar = (refindx[i] + refindx[i - 1]) * 0.5
+        else:
+            refbar = 1.0 + (refindx[i - 1] - refindx[i]) / (np.log((refindx[i - 1] - 1.0) / (refindx[i] - 1.0)))
+        argdth = z[i] / rs - ((refindx[0] - refindx[i]) * costh0 / refindx[i])
+        argth = 0.5 * (a0 + argdth) / r
+        if argth <= 0:
+            raise ValueError("RayTrac_xxx: Ducting at %g degrees" % angle)
+        sint = np.sqrt(r * argth)
+        theta = 2.0 * np.arcsin(sint)
+        if (theta - 2.0 * theta0) <= 0.0:
+            dendth = 2.0 * (sint + sina) * np.cos((theta + theta0) * 0.25)
+            sind4 = (0.5 * argdth - z[i] * argth) / dendth
+            dtheta = 4.0 * np.arcsin(sind4)
+            theta = theta0 + dtheta
+        else:
+            dtheta = theta - theta0
+        tanth = np.tan(theta)
+        cthbar = ((1.0 / tanth) + (1.0 / tanthl)) * 0.5
+        dtau = cthbar * (refindx[i - 1] - refindx[i]) / refbar
+        tau = taul + dtau
+        phi = dtheta + tau
+        ds[i] = np.sqrt((z[i] - z[i - 1]) ** 2 + 4.0 * r * rl * ((np.sin((phi - phil) * 0.5)) ** 2))
+        if dtau != 0.0:
+            dtaua = np.abs(tau - taul)
+            ds[i] = ds[i] * (dtaua / (2.0 * np.sin(dtaua * 0.5)))
+        phil = phi
+        taul = tau
+        rl = r
+        tanthl = tanth
+    return ds
+
+
 def exponential_integration(zeroflg, x, ds, ibeg, iend, factor):
     """RTEquation.exponential_integration [EXT] (TBMODEL EXPINT): log-mean layer value * path.
     Scalar loop kept on purpose -- the branch order is the contract."""
@@ -277,11 +416,13 @@ def bright(hvk, boft):
     return hvk / np.log(1.0 + (1.0 / boft))
 
 
-def tb_cloud_rte(m, z, p, t, rh, frq, angles):
+def tb_cloud_rte(m, z, p, t, rh, frq, angles, denliq=None, denice=None, ray_tracing_on=False):
     """``TbCloudRTE(z,p,t,rh,frq,angles)`` + ``init_absmdl`` + ``satellite=False`` + ``execute()``
-    (PyRTlib_processing.py:123-126): clear sky, plane-parallel, downwelling.
+    (PyRTlib_processing.py:123-126): downwelling; clear sky and plane-parallel unless asked otherwise.
 
     z [km] ascending, p [hPa], t [K], rh [0-1] (ground -> top), frq [GHz], angles = ELEVATION [deg].
+    Opt-in physics the reference leaves at pyrtlib's defaults: ``denliq`` / ``denice``
+    [g m-3 per level] = ``cloudy=True`` + ``init_cloudy``; ``ray_tracing_on`` = ``ray_tracing=True``.
     Returns a dict of flat arrays ordered like pyrtlib's DataFrame (angle-major, frequency-minor).
     """
     z = np.array(z, dtype=np.float64)
@@ -291,29 +432,44 @@ def tb_cloud_rte(m, z, p, t, rh, frq, angles):
     frq = np.asarray(frq, dtype=np.float64)
     angles = np.asarray(angles, dtype=np.float64)
     nl, nf, nang = len(z), len(frq), len(angles)
+    cloudy = denliq is not None or denice is not None
+    denl = np.zeros(nl) if denliq is None else np.asarray(denliq, dtype=np.float64)
+    deni = np.zeros(nl) if denice is None else np.asarray(denice, dtype=np.float64)
+    z0 = z[0]
     z = z - z[0]
     e, rho = vapor(tk, rh)
-    out = {k: np.zeros((nf, nang)) for k in ("tbtotal", "tbatm", "tmr", "tauwet", "taudry")}
+    _dryn, _wetn, refindx = refractivity(p, tk, e)
+    out = {k: np.zeros((nf, nang)) for k in ("tbtotal", "tbatm", "tmr", "tauwet", "taudry", "tauliq", "tauice")}
     lay = np.zeros((nf, nang, nl))
     for k in range(nang):
-        amass = 1 / np.sin(angles[k] * np.pi / 180)
-        ds = np.append([0], np.diff(z)) * amass
+        if ray_tracing_on:
+            ds = ray_tracing(z, refindx, angles[k], z0)
+        else:
+            amass = 1 / np.sin(angles[k] * np.pi / 180)
+            ds = np.append([0], np.diff(z)) * amass
         for j in range(nf):
             awet, adry = clearsky_absorption(m, p, tk, e, frq[j])
             sw, pw = exponential_integration(True, awet, ds, 0, nl, 1)
             sd, pd_ = exponential_integration(True, adry, ds, 0, nl, 1)
-            taulay = pw + pd_ + 0.0 + 0.0          # + liquid + ice, both zero in clear sky
+            if cloudy:
+                aliq, aice = cloudy_absorption(m, tk, denl, deni, frq[j])
+                sl, pl = exponential_integration(False, aliq, ds, 0, nl, 1)
+                si, pi_ = exponential_integration(False, aice, ds, 0, nl, 1)
+            else:
+                sl = si = 0.0
+                pl = pi_ = 0.0
+            taulay = pw + pd_ + pi_ + pl
             boftotl, boftatm, boftmr, _tp, hvk = planck_down(m, frq[j], tk, taulay)
             out["tauwet"][j, k] = sw
             out["taudry"][j, k] = sd
+            out["tauliq"][j, k] = sl
+            out["tauice"][j, k] = si
             out["tbtotal"][j, k] = bright(hvk, boftotl)
             out["tbatm"][j, k] = bright(hvk, boftatm[nl - 1])
             out["tmr"][j, k] = bright(hvk, boftmr)
             lay[j, k] = taulay
     res = {k: v.T.flatten() for k, v in out.items()}
-    res["tmrcld"] = np.zeros(nf * nang)
-    res["tauliq"] = np.zeros(nf * nang)
-    res["tauice"] = np.zeros(nf * nang)
+    res["tmrcld"] = np.zeros(nf * nang)       # cloud radiating temperature: not restated (the reference never reads it)
     res["taulay"] = lay
     return res
 

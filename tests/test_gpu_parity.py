@@ -14,7 +14,8 @@ from oracle import lbl_oracle as lo
 pytestmark = pytest.mark.gpu
 
 TOL_K = 1e-6
-MODELS = ["R98", "R17", "R20", "R20SD", "R24"]
+MODELS = ["R98", "R17", "R20", "R20SD", "R24", "R03", "R16", "R19", "R19SD"]
+GOLDEN_MODELS = ["R98", "R17", "R20", "R20SD", "R24"]      # the table families (the other names alias these)
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "lbl_golden_v1.npz")
 
 
@@ -43,7 +44,7 @@ def test_tb_matches_oracle(gpu_ctx, name, ang):
         assert np.allclose(ex["taulay"][i], zen, rtol=1e-9, atol=1e-16)
 
 
-@pytest.mark.parametrize("name", MODELS)
+@pytest.mark.parametrize("name", GOLDEN_MODELS)
 def test_golden_vectors(gpu_ctx, name):
     with np.load(GOLD, allow_pickle=False) as f:
         g = {k: f[k] for k in f.files}
@@ -807,3 +808,128 @@ def test_minimal_ctypes_binding_as_documented(native_lib):
     ref = lo.tb_cloud_rte(sp.get_model("R24"), z[2], p[2], t[2], rh[2], frq, elev)["tbtotal"]
     assert valid.tolist() == [1, 1, 1] and np.abs(tb[2].ravel() - ref).max() <= TOL_K
     assert lib.mwrt_model_destroy(ctx, mdl) == 0 and lib.mwrt_destroy(ctx) == 0
+
+
+# ---------------------------------------------------------------------------------------------
+# opt-in physics: cloud liquid / ice absorption, spherical refracted ray tracing
+# ---------------------------------------------------------------------------------------------
+def cloud_profiles(P, seed):
+    """Liquid and ice density profiles [g m-3] with the cases the layer rule distinguishes: cloud-free
+    profiles, single levels (zero neighbours on both sides: zeroflg = False gives 0), multi-level clouds,
+    equal adjacent values."""
+    rng = np.random.default_rng(seed)
+    n, nl = P["z"].shape
+    lwc, iwc = np.zeros((n, nl)), np.zeros((n, nl))
+    for i in range(n):
+        if i % 4 == 0:
+            continue                                            # clear column
+        b = int(rng.integers(5, nl // 3)); w = int(rng.integers(1, 12))
+        lwc[i, b:b + w] = rng.uniform(0.05, 0.5, w)
+        if i % 3 == 0:
+            lwc[i, b:b + 2] = 0.2                                # equal neighbours
+        bi = int(rng.integers(nl // 2, nl - 15)); wi = int(rng.integers(1, 10))
+        iwc[i, bi:bi + wi] = rng.uniform(0.005, 0.05, wi)
+    return lwc, iwc
+
+
+@pytest.mark.parametrize("name", ["R98", "R17", "R24"])
+def test_cloudy_matches_oracle(gpu_ctx, name):
+    P = pr.synthetic_profiles(9, 71)
+    lwc, iwc = cloud_profiles(P, 5)
+    m = sp.get_model(name)
+    frq, ang = pr.HATPRO_FRQS, pr.BENCH_ELEVATIONS_7
+    tb, valid, ex = gpu_ctx.tb_batch(name, P["z"], P["p"], P["t"], P["rh"], frq, ang, extras=True, denliq=lwc, denice=iwc)
+    clear, _ = gpu_ctx.tb_batch(name, P["z"], P["p"], P["t"], P["rh"], frq, ang)
+    assert (valid == 1).all()
+    for i in range(9):
+        ref = lo.tb_cloud_rte(m, P["z"][i], P["p"][i], P["t"][i], P["rh"][i], frq, ang, denliq=lwc[i], denice=iwc[i])
+        for k in ("tbtotal", "tbatm", "tmr"):
+            got = tb[i] if k == "tbtotal" else ex[k][i]
+            assert np.abs(got.ravel() - ref[k]).max() <= TOL_K, (k, i)
+        for k in ("tauwet", "taudry", "tauliq", "tauice"):
+            assert np.allclose(ex[k][i].ravel(), ref[k], rtol=1e-10, atol=1e-14), (k, i)
+        zen = ref["taulay"][:, 0, :]                              # angle 0 is zenith
+        assert np.allclose(ex["taulay"][i], zen, rtol=1e-9, atol=1e-15)    # the oracle's own quotient form loses ~1e-10 here
+        if i % 4 == 0:
+            assert np.array_equal(tb[i], clear[i])               # a cloud-free column is the clear-sky result bit for bit
+        else:
+            assert (tb[i, :, 6] > clear[i, :, 6]).all()           # 31.4 GHz warms under liquid
+    # liquid only / ice only, and the zero-cloud call == the clear-sky call bit for bit
+    tb_l, _ = gpu_ctx.tb_batch(name, P["z"], P["p"], P["t"], P["rh"], frq, ang, denliq=lwc)
+    ref = lo.tb_cloud_rte(m, P["z"][1], P["p"][1], P["t"][1], P["rh"][1], frq, ang, denliq=lwc[1])
+    assert np.abs(tb_l[1].ravel() - ref["tbtotal"]).max() <= TOL_K
+    tb_z, _ = gpu_ctx.tb_batch(name, P["z"], P["p"], P["t"], P["rh"], frq, ang, denliq=0 * lwc, denice=0 * iwc)
+    assert np.array_equal(tb_z, clear)
+
+
+def test_cloudy_nan_and_ragged_frequencies(gpu_ctx):
+    P = pr.synthetic_profiles(4, 72, nlev=70)
+    lwc, iwc = cloud_profiles(P, 6)
+    lwc[2, 9] = np.nan
+    frq = np.concatenate([pr.HATPRO_FRQS, [89.0, 150.0, 183.31]])
+    ang = np.array([90.0, 10.0])
+    tb, valid = gpu_ctx.tb_batch("R24", P["z"], P["p"], P["t"], P["rh"], frq, ang, denliq=lwc, denice=iwc)
+    assert list(valid) == [1, 1, 0, 1] and np.isnan(tb[2]).all()
+    m = sp.get_model("R24")
+    for i in (0, 1, 3):
+        ref = lo.tb_cloud_rte(m, P["z"][i], P["p"][i], P["t"][i], P["rh"][i], frq, ang, denliq=lwc[i], denice=iwc[i])
+        assert np.abs(tb[i].ravel() - ref["tbtotal"]).max() <= TOL_K
+
+
+@pytest.mark.parametrize("name", ["R98", "R24"])
+def test_ray_tracing_matches_oracle(gpu_ctx, name):
+    P = pr.synthetic_profiles(5, 73)
+    m = sp.get_model(name)
+    frq, ang = pr.HATPRO_FRQS, pr.REFERENCE_ELEVATIONS                   # 90 ... 4.2 degrees (:37)
+    tb, valid, ex = gpu_ctx.tb_batch(name, P["z"], P["p"], P["t"], P["rh"], frq, ang, extras=True, ray_tracing=True)
+    flat, _ = gpu_ctx.tb_batch(name, P["z"], P["p"], P["t"], P["rh"], frq, ang)
+    assert (valid == 1).all()
+    for i in range(5):
+        ref = lo.tb_cloud_rte(m, P["z"][i], P["p"][i], P["t"][i], P["rh"][i], frq, ang, ray_tracing_on=True)
+        assert np.abs(tb[i].ravel() - ref["tbtotal"]).max() <= TOL_K, i
+        for k in ("tauwet", "taudry"):
+            assert np.allclose(ex[k][i].ravel(), ref[k], rtol=1e-9, atol=1e-14), (k, i)
+    assert np.array_equal(tb[:, 0], flat[:, 0])                          # zenith: the same path
+    assert (tb[:, -1, :7] < flat[:, -1, :7] - 1.0).all()                 # 4.2 deg, K band: shorter path, > 1 K colder
+    # cloud + rays together, and a NaN elevation blanks only its own rows
+    lwc, iwc = cloud_profiles(P, 8)
+    a2 = ang.copy(); a2[3] = np.nan
+    tb2, v2, ex2 = gpu_ctx.tb_batch(name, P["z"], P["p"], P["t"], P["rh"], frq, a2, extras=True, denliq=lwc, denice=iwc,
+                                    ray_tracing=True)
+    keep = ~np.isnan(a2)
+    assert (v2 == 1).all() and np.isnan(tb2[:, 3]).all()
+    for i in (1, 2):
+        ref = lo.tb_cloud_rte(m, P["z"][i], P["p"][i], P["t"][i], P["rh"][i], frq, a2[keep], denliq=lwc[i], denice=iwc[i],
+                              ray_tracing_on=True)
+        assert np.abs(tb2[i][keep].ravel() - ref["tbtotal"]).max() <= TOL_K
+        assert np.allclose(ex2["tauliq"][i][keep].ravel(), ref["tauliq"], rtol=1e-9, atol=1e-14)
+
+
+def test_opt_device_entry_and_spectral_refusal(gpu_ctx):
+    """mwrt_tb_batch_opt_device on torch-owned buffers equals the host-buffer entry; the lane = frequency
+    kernel refuses the options loudly instead of ignoring them."""
+    import torch
+    from mwr_fast_forward_operators_and_lbls_amd._native import MwrtError
+    P = pr.synthetic_profiles(16, 74)
+    lwc, iwc = cloud_profiles(P, 9)
+    frq, ang = pr.HATPRO_FRQS, pr.BENCH_ELEVATIONS_7
+    host, hv = gpu_ctx.tb_batch("R24", P["z"], P["p"], P["t"], P["rh"], frq, ang, denliq=lwc, denice=iwc, ray_tracing=True)
+    dev = torch.device("cuda:0")
+    d = {k: torch.from_numpy(P[k]).to(dev) for k in ("z", "p", "t", "rh")}
+    dl, di = torch.from_numpy(lwc).to(dev), torch.from_numpy(iwc).to(dev)
+    out = torch.empty((16, 7, 14), dtype=torch.float64, device=dev)
+    val = torch.empty(16, dtype=torch.uint8, device=dev)
+    st = torch.cuda.Stream()
+    with torch.cuda.stream(st):
+        gpu_ctx.tb_batch_device("R24", 16, 180, d["z"].data_ptr(), d["p"].data_ptr(), d["t"].data_ptr(), d["rh"].data_ptr(),
+                                frq, ang, out.data_ptr(), val.data_ptr(), stream=st.cuda_stream,
+                                d_denliq=dl.data_ptr(), d_denice=di.data_ptr(), ray_tracing=True)
+        got = out.cpu().numpy()
+    assert np.array_equal(got, host) and np.array_equal(val.cpu().numpy(), hv)
+    gpu_ctx.set_kernel_policy(2)
+    try:
+        with pytest.raises(MwrtError) as ei:
+            gpu_ctx.tb_batch("R24", P["z"], P["p"], P["t"], P["rh"], frq, ang, denliq=lwc)
+        assert ei.value.code == -5
+    finally:
+        gpu_ctx.set_kernel_policy(0)

@@ -121,8 +121,27 @@ def test_tbcloudrte_shim_surface(oracle_ctx, monkeypatch):
     assert np.allclose(lay["taulay"], ref["taulay"], rtol=1e-12, atol=1e-15)
     with pytest.raises(ValueError):
         rte.satellite = "no"
+    # opt-in physics: cloudy needs init_cloudy first (pyrtlib's rule), shapes are checked, ozone stays out
+    with pytest.raises(ValueError):
+        rte.init_cloudy(None, np.zeros(3), np.zeros(3))
+    rte.cloudy = True
+    with pytest.raises(AttributeError):
+        rte.execute()
+    lwc = np.zeros(30); lwc[5:9] = 0.25
+    rte.init_cloudy(np.array([[0.3], [0.6]]), np.zeros(30), lwc)
+    dfc = rte.execute()
+    refc = lo.tb_cloud_rte(sp.get_model("R24"), z, p, t, rh, frq, ang, denliq=lwc, denice=np.zeros(30))
+    assert np.allclose(dfc["tbtotal"].values, refc["tbtotal"], atol=1e-10) and (dfc["tauliq"].values > 0).all()
+    assert (dfc["tbtotal"].values > df["tbtotal"].values).all() and (dfc["tauice"].values == 0).all()
+    rte.cloudy = False
+    rte.ray_tracing = True
+    dfr = rte.execute()
+    refr = lo.tb_cloud_rte(sp.get_model("R24"), z, p, t, rh, frq, ang, ray_tracing_on=True)
+    assert np.allclose(dfr["tbtotal"].values, refr["tbtotal"], atol=1e-10)
+    assert np.array_equal(dfr["tbtotal"].values[:4], df["tbtotal"].values[:4])       # zenith: same path
+    assert (dfr["tbtotal"].values[4:] < df["tbtotal"].values[4:]).all()               # 30 deg: shorter than 1/sin
     with pytest.raises(NotImplementedError):
-        rte.init_cloudy(None, None, None)
+        TbCloudRTE(z, p, t, rh, frq, ang, o3n=np.zeros(30), absmdl="R24", from_sat=False).execute()
 
 
 def test_tbcloudrte_negative_absorption_raises_like_pyrtlib(oracle_ctx):

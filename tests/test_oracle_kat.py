@@ -6,7 +6,7 @@ import numpy as np
 import pytest
 
 from mwr_fast_forward_operators_and_lbls_amd import spectroscopy as sp, profiles as pr
-from oracle import lbl_oracle as lo
+from oracle import lbl_oracle as lo, c_oracle as co
 
 MODELS = ["R98", "R17", "R20", "R20SD", "R24"]
 
@@ -156,3 +156,105 @@ def test_textbook_absorption_anchors():
         assert 27.0 < wet[3] < 30.0, (name, wet[3])
         assert 14.0 < dry[1] < 15.5, (name, dry[1])
         assert 1.25 < dry[2] < 1.7, (name, dry[2])
+
+
+# ---------------------------------------------------------------------------------------------
+# opt-in physics: cloud liquid / ice and ray tracing -- known answers for the oracle
+# ---------------------------------------------------------------------------------------------
+def _one_profile(seed=3, nlev=60):
+    P = pr.synthetic_profiles(1, seed, nlev=nlev)
+    return tuple(P[k][0] for k in ("z", "p", "t", "rh"))
+
+
+@pytest.mark.parametrize("name", ["R98", "R24"])
+def test_zero_cloud_is_clear_sky_bit_for_bit(name):
+    z, p, t, rh = _one_profile()
+    m = sp.get_model(name)
+    frq, ang = pr.HATPRO_FRQS, np.array([90.0, 19.2, 4.2])
+    clear = lo.tb_cloud_rte(m, z, p, t, rh, frq, ang)
+    zero = lo.tb_cloud_rte(m, z, p, t, rh, frq, ang, denliq=np.zeros(60), denice=np.zeros(60))
+    for k in ("tbtotal", "tbatm", "tmr", "tauwet", "taudry", "taulay"):
+        assert np.array_equal(clear[k], zero[k]), k
+    assert (zero["tauliq"] == 0).all() and (zero["tauice"] == 0).all()
+    czero = co.tb_profile_opt(m, z, p, t, rh, frq, ang, np.zeros(60), np.zeros(60), False)
+    cclear = co.tb_profile(m, z, p, t, rh, frq, ang)
+    assert np.array_equal(czero["tbtotal"], cclear["tbtotal"])
+
+
+@pytest.mark.parametrize("name", ["R98", "R24"])
+def test_cloud_opacity_scaling_laws(name):
+    """tau_liq is linear in LWC (abliq is, and the log-mean layer rule is homogeneous of degree 1); in the
+    Rayleigh regime (f << relaxation frequency) liquid absorption goes as f^2; ice goes as f and as IWC."""
+    z, p, t, rh = _one_profile()
+    m = sp.get_model(name)
+    lwc = np.zeros(60); lwc[10:20] = 0.2
+    iwc = np.zeros(60); iwc[40:48] = 0.05
+    ang = np.array([90.0, 30.0])
+    frq = np.array([1.0, 2.0, 22.24, 31.4])
+    a = lo.tb_cloud_rte(m, z, p, t, rh, frq, ang, denliq=lwc, denice=iwc)
+    b = lo.tb_cloud_rte(m, z, p, t, rh, frq, ang, denliq=3 * lwc, denice=2 * iwc)
+    assert np.allclose(b["tauliq"], 3 * a["tauliq"], rtol=1e-13)
+    assert np.allclose(b["tauice"], 2 * a["tauice"], rtol=1e-13)
+    tl = a["tauliq"].reshape(2, 4)
+    assert abs(tl[0, 1] / tl[0, 0] - 4.0) < 0.05                    # f^2 between 1 and 2 GHz
+    ti = a["tauice"].reshape(2, 4)
+    assert np.allclose(ti[0] / ti[0, 0], frq / frq[0], rtol=1e-12)  # ice ~ f
+    assert np.allclose(tl[1] / tl[0], 2.0, rtol=1e-12)              # 30 deg: air mass 2
+    # liquid water path 0.2 g m-3 over the cloud: ~0.03-0.06 K per g m-2 at 31.4 GHz for a warm cloud
+    lwp = float(np.sum(0.5 * (lwc[1:] + lwc[:-1]) * np.diff(z))) * 1000.0   # g m-2
+    clear = lo.tb_cloud_rte(m, z, p, t, rh, frq, ang)
+    dtb = (a["tbtotal"] - clear["tbtotal"]).reshape(2, 4)[0, 3]
+    assert 0.02 < dtb / lwp < 0.08
+
+
+def test_liquid_absorption_models_anchor():
+    """Both liquid models against textbook magnitudes: ~0.2 Np/km per g m-3 at 31.4 GHz, 283 K (Liebe 91:
+    0.18-0.22), rising with falling temperature in the Rayleigh regime; the two models agree within 15 %."""
+    old, new = sp.get_model("R98"), sp.get_model("R24")
+    for T in (283.15, 273.15, 263.15):
+        a0 = lo.liquid_water_absorption(old, 1.0, 31.4, T)
+        a1 = lo.liquid_water_absorption(new, 1.0, 31.4, T)
+        assert 0.12 < a0 < 0.45 and abs(a1 / a0 - 1.0) < 0.15
+    assert lo.liquid_water_absorption(new, 1.0, 31.4, 263.15) > lo.liquid_water_absorption(new, 1.0, 31.4, 283.15)
+    assert lo.liquid_water_absorption(new, 0.0, 31.4, 283.15) == 0.0
+
+
+def test_ray_tracing_known_answers():
+    """(i) within a degree of zenith the path is the layer thickness; (ii) at high elevation the refracted
+    spherical path approaches dz / sin(elev) from below; (iii) without refraction and with a huge Earth
+    radius the flat-earth limit dz / sin(elev) is recovered; (iv) path length grows as elevation drops."""
+    z, p, t, rh = _one_profile(nlev=90)
+    e, _ = lo.vapor(t, rh)
+    _, _, n = lo.refractivity(p, t, e)
+    assert 1.00025 < n[0] < 1.00045 and n[-1] < 1.00001 and (np.diff(n) < 0).sum() > 80      # Thayer: N ~ 300 at ground
+    zz = z - z[0]
+    dz = np.append([0], np.diff(zz))
+    assert np.array_equal(lo.ray_tracing(zz, n, 90.0, z[0]), dz)
+    for elev, tol in ((60.0, 3e-3), (30.0, 2e-2)):          # sphericity: 0.2 % / 1.6 % shorter at 30 km
+        ds = lo.ray_tracing(zz, n, elev, z[0])
+        pp = dz / np.sin(np.deg2rad(elev))
+        assert (ds[1:] <= pp[1:] * (1 + 1e-12)).all() and np.allclose(ds, pp, rtol=tol)
+    lengths = [lo.ray_tracing(zz, n, el, z[0]).sum() for el in (30.0, 19.2, 8.4, 4.2)]
+    assert all(a < b for a, b in zip(lengths, lengths[1:]))
+    am42 = lengths[-1] / zz[-1]
+    assert 9.5 < am42 < 11.0 < 1 / np.sin(np.deg2rad(4.2))          # spherical air mass at 4.2 deg ~10 vs 13.65 flat
+    old = lo.EARTH_RADIUS_KM
+    try:
+        lo.EARTH_RADIUS_KM = 1e12                                     # flat earth ...
+        ds = lo.ray_tracing(zz, np.ones_like(n) + 1e-30, 10.0, z[0])  # ... no refraction
+    finally:
+        lo.EARTH_RADIUS_KM = old
+    assert np.allclose(ds[1:], dz[1:] / np.sin(np.deg2rad(10.0)), rtol=5e-4)
+
+
+def test_ray_traced_tb_c_and_numpy_oracles_agree():
+    z, p, t, rh = _one_profile(nlev=90)
+    m = sp.get_model("R17")
+    frq, ang = pr.HATPRO_FRQS, np.array([90.0, 30.0, 8.4, 4.2])
+    a = lo.tb_cloud_rte(m, z, p, t, rh, frq, ang, ray_tracing_on=True)
+    c = co.tb_profile_opt(m, z, p, t, rh, frq, ang, None, None, True)
+    assert np.abs(a["tbtotal"] - c["tbtotal"]).max() < 1e-9
+    pp = lo.tb_cloud_rte(m, z, p, t, rh, frq, ang)
+    d = (a["tbtotal"] - pp["tbtotal"]).reshape(4, 14)
+    assert (d[0] == 0).all() and (np.abs(d[1]) < 0.3).all() and (d[1] < 0).all()   # zenith identical; 30 deg: <0.3 K colder
+    assert d[3, :7].min() < -1.0                                      # 4.2 deg: K band sees a shorter path, colder sky

@@ -88,11 +88,12 @@ def main(model: str, sets=(), o2_post_scale: float = 1.0):
         "n2_m": 3.55 if model == "R98" else (3.6 if old else 3.22),
         "n2_n": 1.0 if model == "R98" or not old else 1.29,
         "n2_fdep": 0 if model == "R98" else 1, "n2_ptot": 1 if old else 0,
+        "liq_mode": 0 if old else 1,
     }
     # everything above that did not come from a pyrtlib attribute
     out["_unverified_scalars"] = ["h2o_pvap_div", "h2o_den_coef", "h2o_shift_mode", "o2_pvap_div", "o2_wv_factor",
                                   "o2_nonres", "o2_coef", "o2_mix_mode", "o2_line1_dens",
-                                  "n2_l", "n2_m", "n2_n", "n2_fdep", "n2_ptot"]
+                                  "n2_l", "n2_m", "n2_n", "n2_fdep", "n2_ptot", "liq_mode"]
     for k, attr in (("o2_x", "x"), ("o2_wb300", "wb300")):
         if not hasattr(o, attr):
             out["_unverified_scalars"].append(k)
