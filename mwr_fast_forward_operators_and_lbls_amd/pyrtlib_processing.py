@@ -47,6 +47,11 @@ def parse_arguments(argv=None):
                         help="NetCDF (needs xarray) or .npz file with rs and MWR data")
     parser.add_argument("--output", "-o", type=str, default=os.path.expanduser(outpath + outfile),
                         help="Where to save summarized inputs and output TBs")
+    # not in the reference (it runs pyrtlib's defaults): opt-in physics, off unless asked for
+    parser.add_argument("--cloudy", action="store_true",
+                        help="add cloud liquid / ice absorption from Level_Liquid / Level_Ice [kg/kg]")
+    parser.add_argument("--ray-tracing", action="store_true",
+                        help="spherical refracted slant paths instead of dz / sin(elevation)")
     return parser.parse_args(argv)
 
 
@@ -79,6 +84,28 @@ def pack_profiles(ds):
     return z, p, t, rh, ntime, ncrop
 
 
+R_DRY_AIR = 287.06      # J kg-1 K-1, the constant the upstream LWC producer uses (derive_cloud_water.py:73)
+
+
+def cloud_density_g_m3(q_kg_kg, p_hpa, t_k):
+    """Cloud water mixing ratio [kg/kg] -> density [g m-3] (what pyrtlib's init_cloudy takes), with the
+    air density of the upstream producer: rho = p * 100 / (R_L T) (derive_cloud_water.py:88, :92)."""
+    rho_air = np.asarray(p_hpa) * 100.0 / R_DRY_AIR / np.asarray(t_k)
+    return np.asarray(q_kg_kg) * rho_air * 1000.0
+
+
+def pack_clouds(ds, p, t):
+    """``Level_Liquid`` / ``Level_Ice`` (N_Levels, time, Crop) [kg/kg] (preprocessing4all.py:811-812, :1199-1200)
+    -> liquid / ice density [time*Crop][N_Levels] in g m-3, ground -> top like pack_profiles."""
+    out = []
+    for name in ("Level_Liquid", "Level_Ice"):
+        a = np.asarray(ds[name].values, dtype=np.float64)[::-1, :, :]
+        nlev, ntime, ncrop = a.shape
+        q = np.ascontiguousarray(a.reshape(nlev, ntime * ncrop).T)
+        out.append(cloud_density_g_m3(q, p, t))
+    return out
+
+
 def _attrs(tag, tables=None):
     a = {
         'long_name': f'Brightness temperature modelled by {tag}',
@@ -93,9 +120,15 @@ def _attrs(tag, tables=None):
     return a
 
 
-def derive_TBs4PyRTlib(ds, args=None):
+def derive_TBs4PyRTlib(ds, args=None, cloudy=None, ray_tracing=None):
     """Reference :83-197.  All four model runs go to the HIP library in one batched call; there is no
-    other engine."""
+    other engine.
+
+    ``cloudy`` / ``ray_tracing`` (default: ``args.cloudy`` / ``args.ray_tracing`` if present, else off) switch on
+    the physics pyrtlib offers and the reference leaves at its defaults; with both off this is the reference's
+    clear-sky plane-parallel computation."""
+    cloudy = bool(getattr(args, "cloudy", False)) if cloudy is None else bool(cloudy)
+    ray_tracing = bool(getattr(args, "ray_tracing", False)) if ray_tracing is None else bool(ray_tracing)
     frqs = np.array([22.24, 23.04, 23.84, 25.44, 26.24, 27.84, 31.4, 51.26, 52.28,
                      53.86, 54.94, 56.66, 57.3, 58.])
     nf = len(frqs)
@@ -106,7 +139,18 @@ def derive_TBs4PyRTlib(ds, args=None):
 
     # all four models over the same profiles in ONE launch (and one host->device copy of the profiles)
     tables = [spectroscopy.get_model(mdl) for _, mdl in MODEL_RUNS]
-    tb_all, valid_all = _native.default_context().tb_batch_multi(tables, z, p, t, rh, frqs, ang)
+    if cloudy or ray_tracing:
+        # opt-in physics: one launch per model (the multi-model launch is the clear-sky fast path)
+        denliq, denice = pack_clouds(ds, p, t) if cloudy else (None, None)
+        if cloudy:
+            # the producer marks "no cloud information" with NaN (preprocessing4all.py:656-657): treat as no cloud
+            denliq = np.nan_to_num(denliq, nan=0.0)
+            denice = np.nan_to_num(denice, nan=0.0)
+        res = [_native.default_context().tb_batch(tb_, z, p, t, rh, frqs, ang, denliq=denliq, denice=denice,
+                                                  ray_tracing=ray_tracing) for tb_ in tables]
+        tb_all, valid_all = np.stack([r[0] for r in res]), np.stack([r[1] for r in res])
+    else:
+        tb_all, valid_all = _native.default_context().tb_batch_multi(tables, z, p, t, rh, frqs, ang)
     results = {}
     for k, (suffix, mdl) in enumerate(MODEL_RUNS):
         tb, valid = tb_all[k], valid_all[k]
@@ -130,6 +174,9 @@ def derive_TBs4PyRTlib(ds, args=None):
         name = "TBs_PyRTlib_" + tag
         ds[name] = (('time', 'N_Channels', 'elevation', 'Crop'), results[tag])
         ds[name].attrs = _attrs(tag, by_suffix[tag])
+        if cloudy or ray_tracing:
+            ds[name].attrs['physics_options'] = ", ".join(
+                o for o, on in (("cloud liquid/ice absorption", cloudy), ("spherical refracted ray tracing", ray_tracing)) if on)
     return ds
 
 

@@ -75,6 +75,43 @@ def test_derive_tbs_nan_profile_stays_nan(capsys, oracle_ctx):
     assert "NaNs found" in capsys.readouterr().out
 
 
+def test_derive_tbs_opt_in_physics(oracle_ctx):
+    """--cloudy / --ray-tracing: Level_Liquid / Level_Ice [kg/kg] (preprocessing4all.py:811-812) become g m-3 with
+    the producer's air density, NaN cloud info counts as no cloud, and every slot equals one oracle execute()
+    with the same options; with both off the outputs are the reference's clear-sky numbers."""
+    ds, P = make_ds(ntime=2, ncrop=2, nlev=30, elev=(90.0, 8.4))
+    nlev = 30
+    q_liq = np.zeros((nlev, 2, 2)); q_ice = np.zeros((nlev, 2, 2))
+    q_liq[-9:-5, 0, 0] = 2.5e-4                      # kg/kg, index 0 = top: a cloud ~5-9 levels above ground
+    q_liq[:, 1, 1] = np.nan                          # "no cloud information" marker of the producer
+    q_ice[3:6, 0, 1] = 3e-5
+    ds["Level_Liquid"] = (("N_Levels", "time", "Crop"), q_liq)
+    ds["Level_Ice"] = (("N_Levels", "time", "Crop"), q_ice)
+    clear = pp.derive_TBs4PyRTlib(make_ds(ntime=2, ncrop=2, nlev=30, elev=(90.0, 8.4))[0], None)["TBs_PyRTlib_R17"].values
+    args = pp.parse_arguments(["--cloudy", "--ray-tracing"])
+    assert args.cloudy and args.ray_tracing and not pp.parse_arguments([]).cloudy
+    out = pp.derive_TBs4PyRTlib(ds, args)
+    var = out["TBs_PyRTlib_R17"]
+    assert "ray tracing" in var.attrs["physics_options"] and "cloud" in var.attrs["physics_options"]
+    m = sp.get_model("R17")
+    for i in range(2):
+        for j in range(2):
+            z_in = ds["Level_z"].values[::-1, i, j] / 1000
+            p_in = ds["Level_Pressure"].values[::-1, i, j]
+            t_in = ds["Level_Temperature"].values[::-1, i, j]
+            rh_in = ds["Level_RH"].values[::-1, i, j] / 100
+            dl = np.nan_to_num(pp.cloud_density_g_m3(q_liq[::-1, i, j], p_in, t_in))
+            di = np.nan_to_num(pp.cloud_density_g_m3(q_ice[::-1, i, j], p_in, t_in))
+            ref = lo.tb_cloud_rte(m, z_in, p_in, t_in, rh_in, pr.HATPRO_FRQS, np.array([90.0, 8.4]), denliq=dl, denice=di,
+                                  ray_tracing_on=True)["tbtotal"].reshape(2, 14)
+            assert np.allclose(var.values[i, :, :, j], ref.T, rtol=0, atol=1e-9)
+    assert 0.2 < pp.cloud_density_g_m3(2.5e-4, 900.0, 280.0) < 0.35       # 0.25 g/kg at 900 hPa ~ 0.28 g m-3
+    assert (var.values[0, 6, 0, 0] > clear[0, 6, 0, 0] + 1.0)              # 31.4 GHz zenith warms under the liquid cloud
+    only_rays = pp.derive_TBs4PyRTlib(make_ds(ntime=2, ncrop=2, nlev=30, elev=(90.0, 8.4))[0], None, ray_tracing=True)
+    v = only_rays["TBs_PyRTlib_R17"].values
+    assert np.array_equal(v[:, :, 0, :], clear[:, :, 0, :]) and (v[:, :7, 1, :] < clear[:, :7, 1, :]).all()
+
+
 def test_check_for_nans_and_cli():
     a = np.ones(4)
     assert not pp.check_for_nans(a, a, a, a, a, a)
