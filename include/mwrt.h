@@ -218,11 +218,6 @@ int mwrt_absorption_batch_device(mwrt_context* ctx, const mwrt_model* model,
                                  int32_t nf, const double* frq_ghz,
                                  double* d_awet_out, double* d_adry_out, void* stream);
 
-/* Kernel choice for mwrt_tb_batch*: 0 = automatic (currently always the lane = level fused kernel),
- * 1 = always fused, 2 = the lane = frequency "spectral" kernel (at most 16 angles per call).
- * Results agree to rounding; this exists for tests and measurements. */
-int mwrt_set_kernel_policy(mwrt_context* ctx, int policy);
-
 /* Diagnostic: evaluates the kernels' own exp / log / division helpers (fexp, flog, fdiv, fdiv1) on
  * host arrays x[n], y_pos[n] (y > 0), so their accuracy can be checked against libm. */
 int mwrt_selftest_math(mwrt_context* ctx, int32_t n, const double* x, const double* y_pos,

@@ -71,7 +71,6 @@ SIGNATURES = {
                                                   _vp, _i32, _vp, _vp, _vp, _vp]),
     "mwrt_absorption_batch": (ctypes.c_int, [_vp, _vp, _i64, _i32, _vp, _vp, _vp, _i32, _vp, _vp, _vp]),
     "mwrt_absorption_batch_device": (ctypes.c_int, [_vp, _vp, _i64, _i32, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp]),
-    "mwrt_set_kernel_policy": (ctypes.c_int, [_vp, ctypes.c_int]),
     "mwrt_selftest_math": (ctypes.c_int, [_vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp]),
     "mwrt_synchronize": (ctypes.c_int, [_vp, _vp]),
     "mwrt_set_timing": (ctypes.c_int, [_vp, ctypes.c_int]),
@@ -339,11 +338,6 @@ class Context:
             self._handle, self.model(model), int(nprof), int(nlev), _ptr(d_p), _ptr(d_t), _ptr(d_rh),
             frq.size, _ptr(frq), _ptr(d_awet), _ptr(d_adry),
             _stream(stream)), "mwrt_absorption_batch_device")
-
-    @_serialised
-    def set_kernel_policy(self, policy: int):
-        """0 auto, 1 always the lane=level fused kernel, 2 always the lane=frequency spectral kernel."""
-        self._check(self._lib.mwrt_set_kernel_policy(self._handle, int(policy)), "mwrt_set_kernel_policy")
 
     @_serialised
     def selftest_math(self, x, y_pos):

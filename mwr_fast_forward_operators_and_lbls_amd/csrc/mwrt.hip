@@ -86,7 +86,6 @@ struct mwrt_context {
   int device = 0;
   hipStream_t stream = nullptr;
   int lds_max = 65536;
-  int kernel_policy = 0;        // 0 auto, 1 fused, 2 spectral
   // small per-call parameter arrays (frq, airmass): content-keyed device copies.  A copy is never
   // overwritten or freed while the context lives (bar LRU eviction behind a device-wide drain), so
   // launches still queued on ANY stream and captured hipGraphs keep reading valid memory.
@@ -206,40 +205,6 @@ int launch_fused(mwrt_context* c, FusedArgs a, int64_t nprof, hipStream_t st, bo
   if (rc) return rc;
   HIP_TRY(hipGetLastError());
   return MWRT_OK;
-}
-
-template <int NA>
-int launch_spectral_na(mwrt_context* c, const SpectralArgs& a, int64_t nprof, int threads, size_t lds, hipStream_t st) {
-  dim3 grid((unsigned)nprof, (unsigned)((a.nf + threads - 1) / threads)), block(threads);
-  auto k = k_tb_spectral<NA>;
-  HIP_TRY(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  timing_begin(c, st);
-  hipLaunchKernelGGL(k, grid, block, lds, st, a);
-  timing_end(c, st);
-  HIP_TRY(hipGetLastError());
-  return MWRT_OK;
-}
-
-int launch_spectral(mwrt_context* c, const mwrt_model* m, SpectralArgs a, int64_t nprof, hipStream_t st) {
-  int n_sd = 0;
-  for (int k = 0; k < m->h_desc.n_h2o; ++k) n_sd += m->h_desc.h2o_w2[k] > 0.0 ? 1 : 0;
-  a.n_sd = n_sd;
-  a.rec = SP_LEVEL_SCALARS + 4 * m->h_desc.n_o2 + 4 * m->h_desc.n_h2o + 6 * n_sd;
-  const size_t per_level = sizeof(double) * (size_t)(a.rec + SPO_COUNT);
-  const size_t budget = std::min<size_t>((size_t)c->lds_max, 40960);    // 4 workgroups per CU
-  int lc = (int)(budget / per_level);
-  if (lc < 1) return fail(MWRT_ERR_UNSUPPORTED, "line tables too large for the spectral kernel's LDS record");
-  if (lc > a.nlev) lc = a.nlev;
-  a.lc = lc;
-  const size_t lds = per_level * lc;
-  const int threads = std::min(256, ((a.nf + WAVE - 1) / WAVE) * WAVE);
-  HIP_TRY(hipMemsetAsync(a.valid, 1, (size_t)nprof, st));
-  if (a.nang <= 1) return launch_spectral_na<1>(c, a, nprof, threads, lds, st);
-  if (a.nang <= 4) return launch_spectral_na<4>(c, a, nprof, threads, lds, st);
-  if (a.nang <= 7) return launch_spectral_na<7>(c, a, nprof, threads, lds, st);
-  if (a.nang <= 10) return launch_spectral_na<10>(c, a, nprof, threads, lds, st);
-  if (a.nang <= 16) return launch_spectral_na<16>(c, a, nprof, threads, lds, st);
-  return fail(MWRT_ERR_UNSUPPORTED, "spectral kernel supports at most 16 angles per call");
 }
 
 template <int NFC>
@@ -429,20 +394,6 @@ static int tb_launch(mwrt_context* c, int nmodels, const mwrt_model* const* ms, 
   int rc = upload_small(c, c->frq_cache, frq, nf, &dev_frq); if (rc) return rc;
   rc = upload_small(c, c->am_cache, am.data(), nang, &dev_am); if (rc) return rc;
 
-  // automatic = fused: measured on MI355X the spectral kernel loses to it even on the 1000-frequency
-  // grid (profiles/r01_finegrid.txt), so it stays opt-in until it wins
-  const bool spectral = c->kernel_policy == 2;
-  if (spectral) {
-    if (nmodels != 1) return fail(MWRT_ERR_UNSUPPORTED, "the spectral kernel evaluates one model per launch");
-    if (use_opt) return fail(MWRT_ERR_UNSUPPORTED, "cloud / ray-tracing options need the fused kernel (policy 0 or 1)");
-    SpectralArgs sa{};
-    sa.M = ms[0]->d_desc; sa.z = d_z; sa.p = d_p; sa.t = d_t; sa.rh = d_rh;
-    sa.frq = dev_frq; sa.airmass = dev_am;
-    sa.tb = d_tb; sa.valid = d_valid;
-    if (ex) { sa.tbatm = ex->tbatm; sa.tmr = ex->tmr; sa.tauwet = ex->tauwet; sa.taudry = ex->taudry; sa.taulay = ex->taulay; }
-    sa.nlev = nlev; sa.nf = nf; sa.nang = nang;
-    return launch_spectral(c, ms[0], sa, nprof, st);
-  }
   FusedArgs a{};
   for (int i = 0; i < nmodels; ++i) a.Ms[i] = ms[i]->d_desc;
   a.nprof_in = nprof;
@@ -659,12 +610,6 @@ int mwrt_absorption_batch(mwrt_context* c, const mwrt_model* m, int64_t nprof, i
   HIP_TRY(hipMemcpyAsync(awet, dout, nout * sizeof(double), hipMemcpyDeviceToHost, st));
   HIP_TRY(hipMemcpyAsync(adry, dout + nout, nout * sizeof(double), hipMemcpyDeviceToHost, st));
   HIP_TRY(hipStreamSynchronize(st));
-  return MWRT_OK;
-}
-
-int mwrt_set_kernel_policy(mwrt_context* c, int policy) {
-  if (!c || policy < 0 || policy > 2) return fail(MWRT_ERR_INVALID_ARGUMENT, "policy must be 0, 1 or 2");
-  c->kernel_policy = policy;
   return MWRT_OK;
 }
 

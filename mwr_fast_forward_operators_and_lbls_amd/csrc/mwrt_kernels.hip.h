@@ -1294,297 +1294,6 @@ k_tb_fused(const FusedArgs A) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// spectral kernel: lane = FREQUENCY (fine spectral grids, BASELINE config 5: 1000 frequencies)
-//
-// With hundreds of frequencies the lane = level mapping would redo the per-(level, line)
-// transcendentals for every 16-frequency chunk.  Here a workgroup owns (profile, block of up to
-// 256 frequencies): the threads first build the frequency-independent line parameters of LC
-// levels cooperatively in LDS (one (level, line) item per thread), then every lane walks those
-// levels for ITS frequency reading the parameters by LDS broadcast, and carries the layer
-// log-mean and the slant-path recursion for all angles in registers.  No cross-lane traffic,
-// no HBM traffic beyond profile in / TB out.
-// ---------------------------------------------------------------------------------------------
-constexpr int SP_LEVEL_SCALARS = 16;   // per-level scalar slots in the LDS record
-constexpr int SP_MAXA = MWRT_MAX_ANGLES <= 16 ? MWRT_MAX_ANGLES : 16;
-
-struct SpectralArgs {
-  const ModelFlat* M;
-  const double* z; const double* p; const double* t; const double* rh;
-  const double* frq; const double* airmass;
-  double* tb; uint8_t* valid;
-  double* tbatm; double* tmr; double* tauwet; double* taudry; double* taulay;
-  int nlev, nf, nang;
-  int lc;        // levels per LDS chunk
-  int rec;       // doubles per level record = 16 + 4 n_o2 + 4 n_h2o + 6 n_sd
-  int n_sd;      // speed-dependent H2O lines (w2 > 0)
-};
-
-// level scalar slots
-enum { SPS_T = 0, SPS_DZ, SPS_CON0, SPS_WETSCALE, SPS_DRYSCALE, SPS_DFNR, SPS_TH, SPS_N2C, SPS_DRYFLAG,
-       // state shared by the (level, line) items of the build phase
-       SPS_PDA, SPS_PVAP, SPS_TI, SPS_TILN, SPS_TI2, SPS_TH1, SPS_DEN };
-// second scratch row per level for the O2 build state
-enum { SPO_DENS = 0, SPO_PE2, SPO_YMUL, SPO_COUNT };
-
-template <int NA>
-__global__ void __launch_bounds__(256)
-k_tb_spectral(const SpectralArgs A) {
-  extern __shared__ __attribute__((aligned(16))) double lds[];     // 16-B base: wide ds_read stays aligned (guide G17)
-  const int tid = threadIdx.x;
-  const int nthreads = blockDim.x;
-  const int64_t prof = blockIdx.x;
-  const int j = blockIdx.y * nthreads + tid;            // my frequency
-  const bool fact = j < A.nf;
-  const int nlev = A.nlev, nang = A.nang, lc = A.lc, rec = A.rec;
-  const cmodel M = (cmodel)A.M;
-  const cdoubles cfrq = (cdoubles)A.frq;
-  const cdoubles cam = (cdoubles)A.airmass;
-  const int n_o2 = M->n_o2, n_h2o = M->n_h2o;
-  double* recs = lds;                                    // [lc][rec]
-  double* ost = lds + (size_t)lc * rec;                  // [lc][SPO_COUNT] O2 build state
-  __shared__ int s_flag;
-  if (tid == 0) s_flag = 0;
-
-  const double f = cfrq[fact ? j : A.nf - 1];
-  const double f2 = f * f;
-  const double hk = 1e9 * M->planck_h / M->boltzmann_k;
-  const double hvk = f * hk;
-  double fdep = 1.0;
-  if (M->n2_fdep) { const double q = f * (1.0 / 450.0); fdep = 0.5 + fdiv(0.5, 1.0 + q * q); }
-  const bool shifted = M->h2o_shift_mode != 0;
-  const bool second = M->o2_mix_mode != 0;
-  unsigned sdmask = 0;                                   // bit k: H2O line k is speed dependent (uniform)
-  for (int k = 0; k < n_h2o; ++k) sdmask |= (M->h2o_w2[k] > 0.0) ? (1u << k) : 0u;
-
-  double am[NA], Tr[NA], Bt[NA];
-#pragma unroll
-  for (int a = 0; a < NA; ++a) { am[a] = cam[min(a, nang - 1)]; Tr[a] = 1.0; Bt[a] = 0.0; }
-  double Swet = 0.0, Sdry = 0.0;
-  double aw_prev = 0.0, ad_prev = 0.0, b_prev = 0.0;
-  bool neg = false;
-  const double z0 = A.z[prof * nlev];
-  __syncthreads();
-
-  for (int base = 0; base < nlev; base += lc) {
-    const int nl = min(lc, nlev - base);
-    if (base > 0) __syncthreads();                       // everyone is done with the previous chunk
-    // ---- build step A: per-level state ----
-    for (int l = tid; l < nl; l += nthreads) {
-      const int64_t off = prof * nlev + base + l;
-      const double zi = A.z[off], pi = A.p[off], ti_k = A.t[off], rhi = A.rh[off];
-      if (isnan(zi) || isnan(pi) || isnan(ti_k) || isnan(rhi)) atomicOr(&s_flag, 1);
-      double* r = recs + (size_t)l * rec;
-      const double e = goff_gratch_e(ti_k, rhi);
-      const LevelState L = level_state(pi, ti_k, e);
-      // H2O preamble
-      const double pvap = fdiv(L.rho * L.t, M->h2o_pvap_div);
-      const double pda = L.p - pvap;
-      const double lnc = flog(fdiv(M->h2o_reftcon, L.t));
-      const double con0 = (M->h2o_cf * pda * fexp(M->h2o_xcf * lnc) + M->h2o_cs * pvap * fexp(M->h2o_xcs * lnc)) * pvap;
-      const double ti = fdiv(M->h2o_reftline, L.t);
-      const double tiln = flog(ti);
-      // O2 preamble
-      const double th = fdiv(300.0, L.t);
-      const double lnth = flog(th);
-      const double b = fexp(M->o2_x * lnth);
-      const double preswv = fdiv(L.rho * L.t, M->o2_pvap_div);
-      const double presda = L.p - preswv;
-      const double den = 0.001 * (presda * b + M->o2_wv_factor * preswv * th);
-      const double pn2 = M->n2_ptot ? L.p : L.pdry;
-      r[SPS_T] = ti_k;
-      r[SPS_DZ] = (base + l > 0) ? ((zi - z0) - (A.z[off - 1] - z0)) : 0.0;
-      r[SPS_CON0] = con0;
-      r[SPS_WETSCALE] = 3.183e-05 * M->h2o_den_coef * L.rho;
-      r[SPS_DRYSCALE] = M->o2_coef * presda * th * th * th;
-      r[SPS_DFNR] = M->o2_wb300 * den;
-      r[SPS_TH] = th;
-      r[SPS_N2C] = M->n2_n * M->n2_l * pn2 * pn2 * fexp(M->n2_m * lnth);
-      r[SPS_DRYFLAG] = (L.rho > 0.0) ? 1.0 : 0.0;
-      r[SPS_PDA] = pda; r[SPS_PVAP] = pvap; r[SPS_TI] = ti; r[SPS_TILN] = tiln; r[SPS_TI2] = fexp(2.5 * tiln);
-      r[SPS_TH1] = th - 1.0; r[SPS_DEN] = den;
-      double* o = ost + (size_t)l * SPO_COUNT;
-      o[SPO_DENS] = 0.001 * (presda + M->o2_wv_factor * preswv) * th;
-      o[SPO_PE2] = den * den;
-      o[SPO_YMUL] = second ? den : 0.001 * L.p * b;
-    }
-    __syncthreads();
-    if (s_flag) break;                                   // NaN somewhere in this profile
-    // ---- build step B: one (level, line) item per thread ----
-    const int per_level = n_o2 + n_h2o;
-    for (int it = tid; it < nl * per_level; it += nthreads) {
-      const int l = it / per_level;
-      const int k = it - l * per_level;
-      double* r = recs + (size_t)l * rec;
-      if (k < n_o2) {
-        const double* o = ost + (size_t)l * SPO_COUNT;
-        const double th1 = r[SPS_TH1], den = r[SPS_DEN];
-        const double y = o[SPO_YMUL] * (M->o2_y0[k] + M->o2_y1[k] * th1);
-        double dnu = 0.0, gfac = 1.0;
-        if (second) {
-          dnu = o[SPO_PE2] * (M->o2_dnu0[k] + M->o2_dnu1[k] * th1);
-          gfac = 1.0 + o[SPO_PE2] * (M->o2_g0[k] + M->o2_g1[k] * th1);
-        }
-        const double df = M->o2_w300[k] * ((k == 0 && !second && M->o2_line1_dens) ? o[SPO_DENS] : den);
-        const double str = M->o2_s300[k] * fexp(-M->o2_be[k] * th1) * M->o2_rf2[k];
-        const double c1 = M->o2_f[k] + dnu;
-        const double df2 = df * df;
-        const double a = str * df * gfac;
-        const double cb = c1 * (str * y);
-        double* q = r + SP_LEVEL_SCALARS + 4 * k;
-        q[0] = c1; q[1] = df2; q[2] = 2.0 * (a + cb); q[3] = 2.0 * __builtin_fma(c1, c1, df2) * (a - cb);
-      } else {
-        const int kh = k - n_o2;
-        const H2OLine hq = h2o_line(M, kh, r[SPS_PDA], r[SPS_PVAP], r[SPS_TI], r[SPS_TILN], r[SPS_TI2], shifted);
-        double* q = r + SP_LEVEL_SCALARS + 4 * n_o2 + 4 * kh;
-        q[0] = hq.c1; q[1] = hq.wsq; q[2] = hq.sw; q[3] = hq.sbase;
-        if (M->h2o_w2[kh] > 0.0) {                       // speed-dependent line: its slot among the SD records
-          int slot = 0;
-          for (int kk = 0; kk < kh; ++kk) slot += (M->h2o_w2[kk] > 0.0) ? 1 : 0;
-          const double tiln = r[SPS_TILN];
-          double* sdr = r + SP_LEVEL_SCALARS + 4 * n_o2 + 4 * n_h2o + 6 * slot;
-          sdr[0] = hq.w0;
-          sdr[1] = M->h2o_w2[kh] * r[SPS_PDA] * fexp(M->h2o_xw2[kh] * tiln) + M->h2o_w2s[kh] * r[SPS_PVAP] * fexp(M->h2o_xw2s[kh] * tiln);
-          sdr[2] = M->h2o_d2[kh] * r[SPS_PDA] + M->h2o_d2s[kh] * r[SPS_PVAP];
-          sdr[3] = hq.base; sdr[4] = hq.s; sdr[5] = hq.c1;
-        }
-      }
-    }
-    __syncthreads();
-
-    // ---- walk the chunk's levels for my frequency ----
-    for (int l = 0; l < nl; ++l) {
-      const double* r = recs + (size_t)l * rec;
-      // O2 lines: (f^2 P + Q) / (D1 D2); four independent accumulation chains hide the rcp latency
-      double so2a = 0.0, so2b = 0.0, so2c = 0.0, so2d = 0.0;
-      const double* q = r + SP_LEVEL_SCALARS;
-      auto o2_term = [&](const double* qq) {
-        const double c1 = qq[0], df2 = qq[1];
-        const double d1 = f - c1, d2 = f + c1;
-        const double D1 = __builtin_fma(d1, d1, df2);
-        const double D2 = __builtin_fma(d2, d2, df2);
-        const double den12 = D1 * D2;
-        double rr = __builtin_amdgcn_rcp(den12);
-        rr = __builtin_fma(rr, __builtin_fma(-den12, rr, 1.0), rr);
-        return __builtin_fma(f2, qq[2], qq[3]) * rr;
-      };
-      int k = 0;
-      for (; k + 4 <= n_o2; k += 4, q += 16) {
-        so2a += o2_term(q); so2b += o2_term(q + 4); so2c += o2_term(q + 8); so2d += o2_term(q + 12);
-      }
-      for (; k < n_o2; ++k, q += 4) so2a += o2_term(q);
-      const double so2 = (so2a + so2b) + (so2c + so2d);
-      // H2O lines (Lorentz pairs with the 750-GHz cutoff), SD lines' resonant term masked out.
-      // Wave vote per line: when every lane has both terms inside the cutoff the masks drop out.
-      double sh2o = 0.0, sh2b = 0.0;
-      int sd_slot = 0;
-      for (int kh = 0; kh < n_h2o; ++kh, q += 4) {
-        const double c1 = q[0], wsq = q[1];
-        const double d1 = f - c1, d2 = f + c1;
-        const double D1 = __builtin_fma(d1, d1, wsq);
-        const double D2 = __builtin_fma(d2, d2, wsq);
-        const double a1 = fabs(d1);
-        const double den12 = D1 * D2;
-        double rr = __builtin_amdgcn_rcp(den12);
-        rr = __builtin_fma(rr, __builtin_fma(-den12, rr, 1.0), rr);
-        const bool sdl = (sdmask >> kh) & 1u;             // wave-uniform
-        if (!sdl && __all(a1 < 750.0 && fabs(d2) < 750.0)) {
-          sh2o = __builtin_fma((D1 + D2) * rr, q[2], sh2o);
-          sh2b = __builtin_fma(2.0, q[3], sh2b);
-        } else {
-          double sdlim = -1.0;
-          if (sdl) { sdlim = 10.0 * r[SP_LEVEL_SCALARS + 4 * n_o2 + 4 * n_h2o + 6 * sd_slot]; ++sd_slot; }
-          const double m1 = (a1 < 750.0 && !(a1 < sdlim)) ? 1.0 : 0.0;
-          const double m2 = (fabs(d2) < 750.0) ? 1.0 : 0.0;
-          sh2o = __builtin_fma(__builtin_fma(m2, D1, m1 * D2) * rr, q[2], sh2o);
-          sh2b = __builtin_fma(m1 + m2, q[3], sh2b);
-        }
-      }
-      sh2o -= sh2b;
-      // speed-dependent resonant terms
-      for (int sl = 0; sl < A.n_sd; ++sl, q += 6) {
-        const double w0 = q[0], w2 = q[1], delta2 = q[2], sbase = q[3], ss = q[4];
-        const double d1 = f - q[5];
-        if (fabs(d1) < 10.0 * w0) {
-          double r1;
-          if (w2 > 0.0) {
-            const cplx den2 = {w2, -delta2};
-            cplx xc = cdiv(cplx{w0 - 1.5 * w2, d1 + 1.5 * delta2}, den2);
-            cplx xrt = csqrt_principal(xc);
-            cplx w = dcerror_upper(-xrt.im, xrt.re);
-            cplx pxw = cmul(cplx{1.77245385090551603 * xrt.re, 1.77245385090551603 * xrt.im}, w);
-            cplx sd = cdiv(cplx{2.0 * (1.0 - pxw.re), -2.0 * pxw.im}, den2);
-            r1 = sd.re - sbase;
-          } else {
-            r1 = (fabs(d1) < 750.0) ? (fdiv(w0, __builtin_fma(d1, d1, w0 * w0)) - sbase) : 0.0;
-          }
-          sh2o = __builtin_fma(ss, r1, sh2o);
-        }
-      }
-      const double awet = (r[SPS_DRYFLAG] != 0.0) ? (r[SPS_WETSCALE] * sh2o + r[SPS_CON0]) * f2 : 0.0;
-      const double dfnr = r[SPS_DFNR];
-      const double nonres = fdiv(M->o2_nonres * f2 * dfnr, r[SPS_TH] * (f2 + dfnr * dfnr));
-      const double adry = fmax(r[SPS_DRYSCALE] * __builtin_fma(so2, f2, nonres), 0.0) + r[SPS_N2C] * fdep * f2;
-      const double bi = fdiv(1.0, fexp(fdiv(hvk, r[SPS_T])) - 1.0);
-      const int lev = base + l;
-      if (lev > 0) {
-        const double dz = r[SPS_DZ];
-        const double tw = layer_value(awet, aw_prev, neg) * dz;
-        const double td = layer_value(adry, ad_prev, neg) * dz;
-        const double tz = tw + td;
-        Swet += tw; Sdry += td;
-        if (A.taulay && fact) A.taulay[(prof * A.nf + j) * nlev + lev] = tz;
-#pragma unroll
-        for (int a = 0; a < NA; ++a) {
-          const double tl = tz * am[a];
-          const double E = fexp(-tl);
-          const double lay = fdiv(__builtin_fma(bi, E, b_prev), 1.0 + E);
-          Bt[a] = __builtin_fma(lay * Tr[a], 1.0 - E, Bt[a]);
-          Tr[a] *= E;
-        }
-      } else if (A.taulay && fact) {
-        A.taulay[(prof * A.nf + j) * nlev] = 0.0;
-      }
-      aw_prev = awet; ad_prev = adry; b_prev = bi;
-    }
-  }
-  __syncthreads();
-  const double qnan = __builtin_nan("");
-  const bool nan_prof = s_flag & 1;
-  if (nan_prof && tid == 0) A.valid[prof] = 0;
-  if (neg && !nan_prof) A.valid[prof] = 2;               // benign race: every writer stores 2
-  if (!fact) return;
-  const double bbg = fdiv(1.0, fexp(fdiv(hvk, M->t_cosmic)) - 1.0);
-#pragma unroll
-  for (int a = 0; a < NA; ++a) {
-    if (a < nang) {
-      const int64_t o = (prof * nang + a) * A.nf + j;
-      const double S = (Swet + Sdry) * am[a];
-      double tbv, tbatm, tmr;
-      if (nan_prof || neg) {
-        tbv = tbatm = tmr = qnan;
-      } else {
-        double boftotl, boftmr;
-        if (S < TAUMAX) {
-          const double ex = fexp(-S);
-          boftotl = __builtin_fma(bbg, ex, Bt[a]);
-          boftmr = fdiv(Bt[a], 1.0 - ex);
-        } else { boftotl = Bt[a]; boftmr = Bt[a]; }
-        tbv = fdiv(hvk, flog(1.0 + fdiv(1.0, boftotl)));
-        tbatm = fdiv(hvk, flog(1.0 + fdiv(1.0, Bt[a])));
-        tmr = fdiv(hvk, flog(1.0 + fdiv(1.0, boftmr)));
-      }
-      A.tb[o] = tbv;
-      if (A.tbatm) A.tbatm[o] = tbatm;
-      if (A.tmr) A.tmr[o] = tmr;
-      if (A.tauwet) A.tauwet[o] = (nan_prof || neg) ? qnan : Swet * am[a];
-      if (A.taudry) A.taudry[o] = (nan_prof || neg) ? qnan : Sdry * am[a];
-    }
-  }
-  if ((nan_prof || neg) && A.taulay)
-    for (int lev = 0; lev < nlev; ++lev) A.taulay[(prof * A.nf + j) * nlev + lev] = qnan;
-}
-
-// ---------------------------------------------------------------------------------------------
 // K1 alone: awet / adry [nprof][nf][nlev] (RTEquation.clearsky_absorption [EXT])
 // ---------------------------------------------------------------------------------------------
 struct AbsorbArgs {

@@ -1,3 +1,6 @@
+"""Fused kernel on BASELINE configs[4]'s fine grid (1000 frequencies x 7 elevations): 100 profiles and the
+per-GPU share of 1250.  (The lane = frequency "spectral" kernel this script used to compare against was
+deleted in round 2: 13.7 ms against 9.7 ms, profiles/r02_finegrid.txt.)"""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -9,17 +12,15 @@ for nprof in (100, 1250):
     d = {k: torch.from_numpy(P[k]).to(dev) for k in ("z", "p", "t", "rh")}
     out = torch.empty((nprof, len(ang), len(frq)), dtype=torch.float64, device=dev)
     val = torch.empty(nprof, dtype=torch.uint8, device=dev)
-    st = torch.cuda.current_stream().cuda_stream
-    for pol, name in ((1, "fused  "), (2, "spectral")):
-        ctx.set_kernel_policy(pol)
+    st = torch.cuda.Stream()
+    with torch.cuda.stream(st):
         def run():
             ctx.tb_batch_device("R24", nprof, 180, d["z"].data_ptr(), d["p"].data_ptr(), d["t"].data_ptr(), d["rh"].data_ptr(),
-                                frq, ang, out.data_ptr(), val.data_ptr(), stream=st)
-        run(); torch.cuda.synchronize()
+                                frq, ang, out.data_ptr(), val.data_ptr(), stream=st.cuda_stream)
+        run(); st.synchronize()
         ctx.set_timing(True)
         for _ in range(3): run()
-        torch.cuda.synchronize()
-        ms, n = ctx.timing_collect(); ctx.set_timing(False)
-        ev = nprof * 1000 * 7
-        print(f"nprof={nprof} {name}: {ms/n:8.2f} ms  {ev/(ms/n*1e-3):.3e} evals/s", flush=True)
-ctx.set_kernel_policy(0)
+        st.synchronize()
+    ms, n = ctx.timing_collect(); ctx.set_timing(False)
+    ev = nprof * 1000 * 7
+    print(f"nprof={nprof} fused: {ms/n:8.2f} ms  {ev/(ms/n*1e-3):.3e} evals/s", flush=True)
