@@ -175,16 +175,16 @@ void timing_end(mwrt_context* c, hipStream_t st) {
   if (c->timing) { (void)hipEventRecord(c->ev1[c->ev_count % TIMING_RING], st); c->ev_count++; }
 }
 
-template <int NFC, int MAXT, bool OPT>
+template <int NFC, int MAXT, bool FULL>
 int launch_fused_inst(const FusedArgs& a, dim3 grid, dim3 block, size_t lds, hipStream_t st) {
-  auto k = k_tb_fused<NFC, (NFC == 14 ? 7 : 8), MAXT, OPT>;
+  auto k = k_tb_fused<NFC, (NFC == 14 ? 7 : 8), MAXT, FULL>;
   HIP_TRY(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   hipLaunchKernelGGL(k, grid, block, lds, st, a);
   return MWRT_OK;
 }
 
 template <int NFC>
-int launch_fused(mwrt_context* c, FusedArgs a, int64_t nprof, hipStream_t st, bool opt) {
+int launch_fused(mwrt_context* c, FusedArgs a, int64_t nprof, hipStream_t st, bool full) {
   const int threads = ((a.nlev + WAVE - 1) / WAVE) * WAVE;
   const int nchunks = (a.nf + NFC - 1) / NFC;
   size_t lds = 0;
@@ -197,10 +197,12 @@ int launch_fused(mwrt_context* c, FusedArgs a, int64_t nprof, hipStream_t st, bo
   if (!a.write_valid) HIP_TRY(hipMemsetAsync(a.valid, 1, (size_t)nprof, st));
   timing_begin(c, st);
   int rc;
-  if (threads <= 256) rc = opt ? launch_fused_inst<NFC, 256, true>(a, grid, block, lds, st)
-                               : launch_fused_inst<NFC, 256, false>(a, grid, block, lds, st);
-  else rc = opt ? launch_fused_inst<NFC, 1024, true>(a, grid, block, lds, st)
-                : launch_fused_inst<NFC, 1024, false>(a, grid, block, lds, st);
+  // FULL = the instantiation that also carries the by-product columns and the opt-in physics; plain TB
+  // requests (bench, the wrapper's batched call) run the lean TB-only instantiation
+  if (threads <= 256) rc = full ? launch_fused_inst<NFC, 256, true>(a, grid, block, lds, st)
+                                : launch_fused_inst<NFC, 256, false>(a, grid, block, lds, st);
+  else rc = full ? launch_fused_inst<NFC, 1024, true>(a, grid, block, lds, st)
+                 : launch_fused_inst<NFC, 1024, false>(a, grid, block, lds, st);
   timing_end(c, st);
   if (rc) return rc;
   HIP_TRY(hipGetLastError());
@@ -428,10 +430,12 @@ static int tb_launch(mwrt_context* c, int nmodels, const mwrt_model* const* ms, 
     a.amf = c->d_amf.as<double>();
     a.duct = c->d_duct.as<uint8_t>();
   }
+  const bool full = use_opt || (ex && (ex->tbatm || ex->tmr || ex->tauwet || ex->taudry || ex->taulay || ex->tauliq ||
+                                      ex->tauice));
   switch (pick_nfc_fused(c, nlev, nf, nang)) {
-    case 8: return launch_fused<8>(c, a, rows, st, use_opt);
-    case 14: return launch_fused<14>(c, a, rows, st, use_opt);
-    default: return launch_fused<16>(c, a, rows, st, use_opt);
+    case 8: return launch_fused<8>(c, a, rows, st, full);
+    case 14: return launch_fused<14>(c, a, rows, st, full);
+    default: return launch_fused<16>(c, a, rows, st, full);
   }
 }
 

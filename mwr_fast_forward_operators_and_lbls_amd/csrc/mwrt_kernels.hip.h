@@ -748,37 +748,38 @@ __device__ __forceinline__ void dry_absorb(cmodel M, const LevelState& L, const 
 // Branch order is the contract.  Returns NaN-flag through `neg`.
 //
 // The log-mean itself: with s = (x1 - x0)/(x1 + x0),  ln(x1/x0) = 2 atanh(s), so
-//   (x1 - x0)/ln(x1/x0) = (x1 + x0)/2 / (1 + s^2/3 + s^4/5 + ...).
+//   (x1 - x0)/ln(x1/x0) = (x1 + x0)/2 * s/atanh(s),   s/atanh(s) = 1 - s^2/3 - 4 s^4/45 - ...
 // Adjacent levels of a sounding differ by a few percent, so |s| <= LOGMEAN_SMALL_S for a whole wave is
 // the usual case (wave vote): one division and a 10-term series instead of a division, a full log
 // (frexp, second division, series) and a third division.  It is also better conditioned than the
 // quotient form, which loses up to 1e-7 relative when x1 - x0 is just above the 1e-9 switch.
-constexpr double LOGMEAN_SMALL_S = 0.1715;      // |s| <= this: series truncation s^22/23 < 7e-19
+constexpr double LOGMEAN_SMALL_S = 0.1715;      // |s| <= this: series truncation < 1.1e-19
 template <bool ZEROFLG = true>
 __device__ __forceinline__ double layer_value(double x1, double x0, bool& neg) {
   const double d = x1 - x0;
   const double sm = x1 + x0;
-  const bool negative = x0 < 0.0 || x1 < 0.0;
+  const bool negative = (x0 < 0.0) | (x1 < 0.0);
   const bool same = fabs(d) < 1e-09;
   const bool zero = x0 == 0.0 || x1 == 0.0;
   const bool special = negative || same || zero;
   double r;
   const double s = fdiv1(d, sm);
   if (__all(special || fabs(s) <= LOGMEAN_SMALL_S)) {
+    // s / atanh(s) = 1 - z/3 - 4 z^2/45 - 44 z^3/945 - ... (z = s^2; coefficients by series inversion,
+    // truncation after z^10 < 1.1e-19 at |s| = 0.1715): the log-mean is (x1 + x0)/2 times this
     const double z = s * s;
-    double p = 4.3478260869565216e-02;                    // 1/23
-    MWRT_FMA_SC(p, z, 4.7619047619047616e-02);            // 1/21
-    MWRT_FMA_SC(p, z, 5.2631578947368418e-02);            // 1/19
-    MWRT_FMA_SC(p, z, 5.8823529411764705e-02);            // 1/17
-    MWRT_FMA_SC(p, z, 6.6666666666666666e-02);            // 1/15
-    MWRT_FMA_SC(p, z, 7.6923076923076927e-02);            // 1/13
-    MWRT_FMA_SC(p, z, 9.0909090909090912e-02);            // 1/11
-    MWRT_FMA_SC(p, z, 1.1111111111111110e-01);            // 1/9
-    MWRT_FMA_SC(p, z, 1.4285714285714285e-01);            // 1/7
-    MWRT_FMA_SC(p, z, 2.0000000000000001e-01);            // 1/5
-    MWRT_FMA_SC(p, z, 3.3333333333333331e-01);            // 1/3
-    p = __builtin_fma(p, z, 1.0);
-    r = fdiv1(0.5 * sm, p);
+    double q = -8.2312065673505011548e-03;
+    MWRT_FMA_SC(q, z, -9.5160731945278989134e-03);
+    MWRT_FMA_SC(q, z, -1.1203745637718733130e-02);
+    MWRT_FMA_SC(q, z, -1.3502765051265933100e-02);
+    MWRT_FMA_SC(q, z, -1.6787551856334925118e-02);
+    MWRT_FMA_SC(q, z, -2.1796804019026241248e-02);
+    MWRT_FMA_SC(q, z, -3.0194003527336860670e-02);
+    MWRT_FMA_SC(q, z, -4.6560846560846560847e-02);
+    MWRT_FMA_SC(q, z, -8.8888888888888888889e-02);
+    MWRT_FMA_SC(q, z, -3.3333333333333333333e-01);
+    q = __builtin_fma(q, z, 1.0);
+    r = (0.5 * sm) * q;
   } else {
     r = fdiv1(d, flog(fdiv(x1, x0)));
   }
@@ -792,7 +793,7 @@ __device__ __forceinline__ double layer_value(double x1, double x0, bool& neg) {
 // ---------------------------------------------------------------------------------------------
 // Opt-in physics the reference leaves at pyrtlib's defaults: cloud liquid / ice
 // absorption (cloudy=True + init_cloudy) and spherical refracted ray tracing (ray_tracing=True).
-// Only the OPT instantiations of the fused kernel contain this code; the clear-sky kernel is untouched.
+// Only the FULL instantiations of the fused kernel contain this code; the TB-only kernel is untouched.
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ cplx clog_(cplx w) {       // principal complex logarithm
   return {0.5 * flog(__builtin_fma(w.re, w.re, w.im * w.im)), atan2(w.im, w.re)};
@@ -973,7 +974,7 @@ struct FusedArgs {
   int nlev, nf, nang;
   int write_valid;         // 1: this launch has one workgroup per profile and sets valid = 1 itself
   LaunchGeom g;
-  // opt-in physics (read by the OPT instantiations only)
+  // by-products and opt-in physics (read by the FULL instantiations only; null / 0 otherwise)
   const double* denliq; const double* denice;   // [nprof][nlev] g m-3, either may be null
   const double* amf;       // [nprof][nang][nlev] ray-traced path factor ds/dz, or null (plane-parallel)
   const uint8_t* duct;     // [nprof] 1: a ray of this profile was trapped (valid = 3)
@@ -1006,7 +1007,7 @@ __device__ __forceinline__ void blank_outputs(const FusedArgs& A, int64_t prof, 
 #ifndef MWRT_MIN_WAVES
 #define MWRT_MIN_WAVES 1
 #endif
-template <int NFC, int NFK, int MAXT, bool OPT = false>
+template <int NFC, int NFK, int MAXT, bool FULL = false>
 __global__ void __launch_bounds__(MAXT, (MAXT <= 256 ? MWRT_MIN_WAVES : 1))
 k_tb_fused(const FusedArgs A) {
   static_assert(NFC % NFK == 0, "NFC must be a multiple of NFK");
@@ -1056,7 +1057,7 @@ k_tb_fused(const FusedArgs A) {
   const double zi = A.z[off], pi = A.p[off], ti = A.t[off], rhi = A.rh[off];
   if (active && (isnan(zi) || isnan(pi) || isnan(ti) || isnan(rhi))) atomicOr(&s_flag, 1);
   double denl = 0.0, deni = 0.0;
-  if constexpr (OPT) {
+  if constexpr (FULL) {
     if (A.denliq) denl = A.denliq[off];
     if (A.denice) deni = A.denice[off];
     if (active && (isnan(denl) || isnan(deni))) atomicOr(&s_flag, 1);
@@ -1100,8 +1101,8 @@ k_tb_fused(const FusedArgs A) {
     }
   }
   // cloud liquid / ice (opt-in): same layer rule with zeroflg = False; tau = ((wet + dry) + ice) + liquid
-  double tl[OPT ? NFC : 1], tci[OPT ? NFC : 1];
-  if constexpr (OPT) {
+  double tl[FULL ? NFC : 1], tci[FULL ? NFC : 1];
+  if constexpr (FULL) {
 #pragma unroll
     for (int j = 0; j < NFC; ++j) { tl[j] = 0.0; tci[j] = 0.0; }
     if (A.denliq || A.denice) {
@@ -1135,17 +1136,17 @@ k_tb_fused(const FusedArgs A) {
     return;
   }
   const double hk = 1e9 * M->planck_h / M->boltzmann_k;
-  if (A.taulay && active) {
+  // The TB-only instantiation (FULL = false) carries none of the by-product code: the compiler would
+  // otherwise evaluate tbatm / tmr speculatively and keep the opacity sums' registers alive.
+  bool want_tau = false;
+  if constexpr (FULL) {
+    if (A.taulay && active) {
 #pragma unroll
-    for (int j = 0; j < NFC; ++j)
-      if (j < nfc) {
-        double tz = tw[j] + td[j];
-        if constexpr (OPT) tz = (tz + tci[j]) + tl[j];
-        A.taulay[(prof * A.nf + jbase + j) * nlev + tid] = tz;
-      }
+      for (int j = 0; j < NFC; ++j)
+        if (j < nfc) A.taulay[(prof * A.nf + jbase + j) * nlev + tid] = ((tw[j] + td[j]) + tci[j]) + tl[j];
+    }
+    want_tau = (A.tauwet != nullptr) || (A.taudry != nullptr) || (A.tauliq != nullptr) || (A.tauice != nullptr);
   }
-  bool want_tau = (A.tauwet != nullptr) || (A.taudry != nullptr);
-  if constexpr (OPT) want_tau = want_tau || (A.tauliq != nullptr) || (A.tauice != nullptr);
   const int nseg = A.g.nseg, seglen = A.g.seglen;
 
   // ---- phase K2: slant-path RTE (RTEquation.planck, from_sat = False [EXT]), NFK rows at a time ----
@@ -1160,26 +1161,26 @@ k_tb_fused(const FusedArgs A) {
       for (int jj = 0; jj < NFK; ++jj) {
         const int j = h * NFK + jj;
         double tz = tw[j] + td[j];
-        if constexpr (OPT) tz = (tz + tci[j]) + tl[j];
+        if constexpr (FULL) tz = (tz + tci[j]) + tl[j];
         tau[jj * ld + tid] = tz;
         bof[jj * ld + tid] = planck_b(sfq[2 * j] * hkt);
       }
     }
     // optional zenith opacity sums (tauwet / taudry columns); deterministic order
-    double swet[NFK], sdry[NFK], sliq[OPT ? NFK : 1], sice[OPT ? NFK : 1];
-    const bool rays = OPT && A.amf != nullptr;
-    if (want_tau && !rays) {
+    double swet[FULL ? NFK : 1], sdry[FULL ? NFK : 1], sliq[FULL ? NFK : 1], sice[FULL ? NFK : 1];
+    const bool rays = FULL && A.amf != nullptr;
+    if constexpr (FULL) {
+      if (want_tau && !rays) {
 #pragma unroll
-      for (int jj = 0; jj < NFK; ++jj) {
-        swet[jj] = block_sum(tw[h * NFK + jj], scratch, tid, nthreads);
-        sdry[jj] = block_sum(td[h * NFK + jj], scratch, tid, nthreads);
-        if constexpr (OPT) {
+        for (int jj = 0; jj < NFK; ++jj) {
+          swet[jj] = block_sum(tw[h * NFK + jj], scratch, tid, nthreads);
+          sdry[jj] = block_sum(td[h * NFK + jj], scratch, tid, nthreads);
           sliq[jj] = block_sum(tl[h * NFK + jj], scratch, tid, nthreads);
           sice[jj] = block_sum(tci[h * NFK + jj], scratch, tid, nthreads);
         }
       }
     }
-    if constexpr (OPT) {
+    if constexpr (FULL) {
       if (want_tau && rays) {
         // ray-traced paths: the opacity columns are sums of layer value x path factor, one species at a
         // time through the tau rows (the DataFrame path of a single execute(); not a throughput path)
@@ -1228,11 +1229,11 @@ k_tb_fused(const FusedArgs A) {
       const double* tj = tau + jj * ld;
       const double* bj = bof + jj * ld;
       const double* fr = nullptr;
-      if constexpr (OPT) fr = A.amf ? A.amf + (pin * nang + a) * nlev : nullptr;
+      if constexpr (FULL) fr = A.amf ? A.amf + (pin * nang + a) * nlev : nullptr;
       double T = 1.0, B = 0.0, S = 0.0;
       double bprev = (lo < nlev) ? bj[lo - 1] : 0.0;
       for (int i = lo; i < hi; ++i) {
-        const double tl = tj[i] * ((OPT && fr) ? fr[i] : am);
+        const double tl = tj[i] * ((FULL && fr) ? fr[i] : am);
         const double E = __all(fabs(tl) <= EXP_SMALL_X) ? fexp_small(-tl) : fexp(-tl);
         const double bi = bj[i];
         const double lay = fdiv1(__builtin_fma(bi, E, bprev), 1.0 + E);
@@ -1261,32 +1262,29 @@ k_tb_fused(const FusedArgs A) {
         const double ex = fexp(-S);
         const double bbg = fdiv(1.0, fexp(fdiv(hvk, M->t_cosmic)) - 1.0);
         boftotl = __builtin_fma(bbg, ex, B);
-        boftmr = fdiv(B, 1.0 - ex);
+        boftmr = FULL ? fdiv(B, 1.0 - ex) : 0.0;
       } else {
         boftotl = B; boftmr = B;
       }
       const int64_t o = (prof * nang + a) * A.nf + jbase + j;
       A.tb[o] = fdiv(hvk, flog(1.0 + fdiv(1.0, boftotl)));
-      if (A.tbatm) A.tbatm[o] = fdiv(hvk, flog(1.0 + fdiv(1.0, B)));
-      if (A.tmr) A.tmr[o] = fdiv(hvk, flog(1.0 + fdiv(1.0, boftmr)));
-      if (want_tau && !rays) {
-        const double am = cam[a];
-        double sw = 0.0, sd = 0.0, sl = 0.0, si = 0.0;
+      if constexpr (FULL) {
+        if (A.tbatm) A.tbatm[o] = fdiv(hvk, flog(1.0 + fdiv(1.0, B)));
+        if (A.tmr) A.tmr[o] = fdiv(hvk, flog(1.0 + fdiv(1.0, boftmr)));
+        if (want_tau && !rays) {
+          const double am = cam[a];
+          double sw = 0.0, sd = 0.0, sl = 0.0, si = 0.0;
 #pragma unroll
-        for (int q2 = 0; q2 < NFK; ++q2) if (q2 == jj) {
-          sw = swet[q2]; sd = sdry[q2];
-          if constexpr (OPT) { sl = sliq[q2]; si = sice[q2]; }
-        }
-        if (A.tauwet) A.tauwet[o] = sw * am;
-        if (A.taudry) A.taudry[o] = sd * am;
-        if constexpr (OPT) {
+          for (int q2 = 0; q2 < NFK; ++q2) if (q2 == jj) { sw = swet[q2]; sd = sdry[q2]; sl = sliq[q2]; si = sice[q2]; }
+          if (A.tauwet) A.tauwet[o] = sw * am;
+          if (A.taudry) A.taudry[o] = sd * am;
           if (A.tauliq) A.tauliq[o] = sl * am;
           if (A.tauice) A.tauice[o] = si * am;
         }
       }
     }
   }
-  if constexpr (OPT) {
+  if constexpr (FULL) {
     // a trapped ray (ducting) leaves its angle NaN and marks the profile 3
     if (A.duct && A.duct[pin]) { if (tid == 0) A.valid[prof] = 3; return; }
   }
