@@ -201,6 +201,10 @@ int launch_fused(mwrt_context* c, FusedArgs a, int64_t nprof, hipStream_t st, bo
   // requests (bench, the wrapper's batched call) run the lean TB-only instantiation
   if (threads <= 256) rc = full ? launch_fused_inst<NFC, 256, true>(a, grid, block, lds, st)
                                 : launch_fused_inst<NFC, 256, false>(a, grid, block, lds, st);
+  // taller profiles: 512-thread workgroups get 256 VGPRs per lane (no scratch); only > 512 levels fall to the
+  // 1024-thread instantiation, whose 128-VGPR cap spills (profiles/r02_tall_profiles.txt)
+  else if (threads <= 512) rc = full ? launch_fused_inst<NFC, 512, true>(a, grid, block, lds, st)
+                                     : launch_fused_inst<NFC, 512, false>(a, grid, block, lds, st);
   else rc = full ? launch_fused_inst<NFC, 1024, true>(a, grid, block, lds, st)
                  : launch_fused_inst<NFC, 1024, false>(a, grid, block, lds, st);
   timing_end(c, st);
@@ -216,6 +220,7 @@ int launch_absorb(mwrt_context* c, AbsorbArgs a, int64_t nprof, hipStream_t st) 
   dim3 grid((unsigned)nprof, (unsigned)nchunks), block(threads);
   timing_begin(c, st);
   if (threads <= 256) hipLaunchKernelGGL((k_absorb<NFC, 256>), grid, block, 0, st, a);
+  else if (threads <= 512) hipLaunchKernelGGL((k_absorb<NFC, 512>), grid, block, 0, st, a);
   else hipLaunchKernelGGL((k_absorb<NFC, 1024>), grid, block, 0, st, a);
   timing_end(c, st);
   HIP_TRY(hipGetLastError());
