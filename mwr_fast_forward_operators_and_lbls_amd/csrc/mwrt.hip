@@ -428,9 +428,9 @@ static int tb_launch(mwrt_context* c, int nmodels, const mwrt_model* const* ms, 
       HIP_TRY(c->d_duct.reserve((size_t)nprof));
     }
     HIP_TRY(hipMemsetAsync(c->d_duct.p, 0, (size_t)nprof, st));
-    const int64_t nrays = nprof * nang;
-    hipLaunchKernelGGL(k_ray_paths, dim3((unsigned)((nrays + 63) / 64)), dim3(64), 0, st, d_z, d_p, d_t, d_rh, nprof,
-                       (int)nlev, dev_elev, (int)nang, c->d_amf.as<double>(), c->d_duct.as<uint8_t>());
+    const int rthreads = ((nlev + WAVE - 1) / WAVE) * WAVE;
+    hipLaunchKernelGGL(k_ray_paths, dim3((unsigned)nprof), dim3(rthreads), 0, st, d_z, d_p, d_t, d_rh, (int)nlev, dev_elev,
+                       (int)nang, c->d_amf.as<double>(), c->d_duct.as<uint8_t>());
     HIP_TRY(hipGetLastError());
     a.amf = c->d_amf.as<double>();
     a.duct = c->d_duct.as<uint8_t>();

@@ -872,86 +872,102 @@ __device__ __forceinline__ double thayer_refindex(double p, double tk, double e)
 }
 
 // RTEquation.ray_tracing [EXT] (TBMODEL RAYTRAC: Dutton, Thayer & Westwater after Bean & Dutton fig. 3.20).
-// One thread per (profile, angle) walks the levels in the reference's own order and stores the PATH FACTOR
-// ds_i / dz_i per layer, amf [nprof][nang][nlev] (entry 0 = 0): the slant-path integration multiplies the
-// zenith layer optical depth by it, exactly where the plane-parallel path multiplies by 1/sin(elev).
-// A trapped ray (ducting) gives NaN factors for that angle and duct[profile] = 1.  Ordinary libm calls: this
-// pre-kernel is ~0.1 % of the arithmetic of the opt-in path and is not tuned.
+// Stores the PATH FACTOR ds_i / dz_i per layer, amf [nprof][nang][nlev] (entry 0 = 0): the slant-path
+// integration multiplies the zenith layer optical depth by it, exactly where the plane-parallel path
+// multiplies by 1/sin(elev).
+//
+// Workgroup = profile, LANE = LEVEL, loop over angles.  The reference walks the levels serially, carrying
+// (phi, tau, r, tan theta) of the level below; but theta_i depends only on level i and the ground, and the
+// carried sums enter ds only through differences,
+//     phi_i - phi_{i-1} = (dtheta_i - dtheta_{i-1}) + dtau_i,      |tau_i - tau_{i-1}| = |dtau_i|,
+// so every layer needs just its lower neighbour (one __shfl_up, wave seams through LDS): no scan, and the
+// differences are formed directly instead of from two running sums (slightly better conditioned than the
+// reference's own order; agreement ~1e-12 relative in ds).  A trapped ray (ducting: argth <= 0 at any level)
+// gives NaN factors for that angle and duct[profile] = 1.  libm calls (asin, tan, ...): ~3 % of the opt-in
+// path's arithmetic, not tuned further.
 constexpr double EARTH_RADIUS_KM = 6370.949;
-__global__ void __launch_bounds__(64)
+__global__ void __launch_bounds__(1024)
 k_ray_paths(const double* __restrict__ z, const double* __restrict__ p, const double* __restrict__ t,
-            const double* __restrict__ rh, int64_t nprof, int nlev, const double* __restrict__ elev_deg, int nang,
+            const double* __restrict__ rh, int nlev, const double* __restrict__ elev_deg, int nang,
             double* __restrict__ amf, uint8_t* __restrict__ duct) {
-  const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (g >= nprof * nang) return;
-  const int64_t prof = g / nang;
-  const int a = (int)(g - prof * nang);
-  const double* zp = z + prof * nlev; const double* pp = p + prof * nlev;
-  const double* tp = t + prof * nlev; const double* rp = rh + prof * nlev;
-  double* out = amf + g * nlev;
-  const double angle = elev_deg[a];
+  __shared__ double seam[16][3];            // last lane of each wave: refractive index, tan(theta), dtheta
+  const int64_t prof = blockIdx.x;
+  const int tid = threadIdx.x, lane = tid & (WAVE - 1), wave = tid / WAVE;
+  const bool active = tid < nlev;
+  const int64_t off = prof * nlev + (active ? tid : 0);
   const double qnan = __builtin_nan("");
-  out[0] = 0.0;
-  bool bad = isnan(angle);
-  for (int i = 0; i < nlev; ++i) bad = bad || isnan(zp[i]) || isnan(pp[i]) || isnan(tp[i]) || isnan(rp[i]);
-  if (bad) { for (int i = 1; i < nlev; ++i) out[i] = qnan; return; }   // NaN inputs are the main kernel's business
-  if ((angle >= 89.0 && angle <= 91.0) || (angle >= -91.0 && angle <= -89.0)) {
-    for (int i = 1; i < nlev; ++i) out[i] = (zp[i] - zp[i - 1] != 0.0) ? 1.0 : 0.0;
-    return;
-  }
-  const double z0 = zp[0];
-  const double theta0 = angle * (M_PI / 180.0);
+  const double z0 = z[prof * nlev];
+  const double zi = z[off] - z0;
+  const double pi = p[off], ti = t[off], rhi = rh[off];
+  const bool bad_prof = __syncthreads_or(active && (isnan(zi) || isnan(pi) || isnan(ti) || isnan(rhi)));
+  const double ni = thayer_refindex(pi, ti, goff_gratch_e(ti, rhi));
+  // neighbour level i-1 (level-only quantities)
+  if (lane == WAVE - 1) seam[wave][0] = ni;
+  __syncthreads();
+  double nprev = __shfl_up(ni, 1, WAVE);
+  double zprev = __shfl_up(zi, 1, WAVE);
+  if (lane == 0 && wave > 0) { nprev = seam[wave - 1][0]; zprev = z[off - 1] - z0; }
+  const double n0 = thayer_refindex(p[prof * nlev], t[prof * nlev], goff_gratch_e(t[prof * nlev], rh[prof * nlev]));
   const double rs = EARTH_RADIUS_KM + 0.0 + z0;
-  const double costh0 = cos(theta0), sina = sin(theta0 * 0.5);
-  const double a0 = 2.0 * (sina * sina);
-  const double n0 = thayer_refindex(pp[0], tp[0], goff_gratch_e(tp[0], rp[0]));
-  double phil = 0.0, taul = 0.0, rl = rs, tanthl = tan(theta0), nprev = n0, zprev = 0.0;
-  bool trapped = false;
-  for (int i = 1; i < nlev; ++i) {
-    const double zi = zp[i] - z0;
-    const double ni = thayer_refindex(pp[i], tp[i], goff_gratch_e(tp[i], rp[i]));
-    double dsi = qnan;
-    if (!trapped) {
-      const double r = EARTH_RADIUS_KM + zi + z0;
-      double refbar;
-      if (ni == nprev || ni == 1.0 || nprev == 1.0) refbar = (ni + nprev) * 0.5;
-      else refbar = 1.0 + (nprev - ni) / (log((nprev - 1.0) / (ni - 1.0)));
-      const double argdth = zi / rs - ((n0 - ni) * costh0 / ni);
-      const double argth = 0.5 * (a0 + argdth) / r;
-      if (argth <= 0.0) {
-        trapped = true;
+  const double r = EARTH_RADIUS_KM + zi + z0;
+  const double rl = EARTH_RADIUS_KM + zprev + z0;
+  const double dz = zi - zprev;
+  double refbar;
+  if (ni == nprev || ni == 1.0 || nprev == 1.0) refbar = (ni + nprev) * 0.5;
+  else refbar = 1.0 + (nprev - ni) / (log((nprev - 1.0) / (ni - 1.0)));
+  for (int a = 0; a < nang; ++a) {
+    double* out = amf + (prof * nang + a) * nlev;
+    const double angle = elev_deg[a];
+    if (bad_prof || isnan(angle)) {            // NaN inputs are the main kernel's business
+      if (active) out[tid] = tid == 0 ? 0.0 : qnan;
+      continue;
+    }
+    if ((angle >= 89.0 && angle <= 91.0) || (angle >= -91.0 && angle <= -89.0)) {
+      if (active) out[tid] = (tid > 0 && dz != 0.0) ? 1.0 : 0.0;
+      continue;
+    }
+    const double theta0 = angle * (M_PI / 180.0);
+    const double costh0 = cos(theta0), sina = sin(theta0 * 0.5);
+    const double a0 = 2.0 * (sina * sina);
+    // my level: theta_i, dtheta_i (level 0 is the ground: theta0, 0)
+    const double argdth = zi / rs - ((n0 - ni) * costh0 / ni);
+    const double argth = 0.5 * (a0 + argdth) / r;
+    const bool trapped_here = active && tid > 0 && !(argth > 0.0);
+    double theta = theta0, dtheta = 0.0;
+    if (tid > 0 && argth > 0.0) {
+      const double sint = sqrt(r * argth);
+      theta = 2.0 * asin(sint);
+      if ((theta - 2.0 * theta0) <= 0.0) {
+        const double dendth = 2.0 * (sint + sina) * cos((theta + theta0) * 0.25);
+        const double sind4 = (0.5 * argdth - zi * argth) / dendth;
+        dtheta = 4.0 * asin(sind4);
+        theta = theta0 + dtheta;
       } else {
-        const double sint = sqrt(r * argth);
-        double theta = 2.0 * asin(sint), dtheta;
-        if ((theta - 2.0 * theta0) <= 0.0) {
-          const double dendth = 2.0 * (sint + sina) * cos((theta + theta0) * 0.25);
-          const double sind4 = (0.5 * argdth - zi * argth) / dendth;
-          dtheta = 4.0 * asin(sind4);
-          theta = theta0 + dtheta;
-        } else {
-          dtheta = theta - theta0;
-        }
-        const double tanth = tan(theta);
-        const double cthbar = ((1.0 / tanth) + (1.0 / tanthl)) * 0.5;
-        const double dtau = cthbar * (nprev - ni) / refbar;
-        const double tau = taul + dtau;
-        const double phi = dtheta + tau;
-        const double sh = sin((phi - phil) * 0.5);
-        dsi = sqrt((zi - zprev) * (zi - zprev) + 4.0 * r * rl * (sh * sh));
-        if (dtau != 0.0) {
-          const double dtaua = fabs(tau - taul);
-          dsi = dsi * (dtaua / (2.0 * sin(dtaua * 0.5)));
-        }
-        phil = phi; taul = tau; rl = r; tanthl = tanth;
+        dtheta = theta - theta0;
       }
     }
-    const double dz = zi - zprev;
-    out[i] = trapped ? qnan : ((dz != 0.0) ? dsi / dz : 0.0);
-    nprev = ni; zprev = zi;
-  }
-  if (trapped) {
-    for (int i = 1; i < nlev; ++i) out[i] = qnan;       // pyrtlib gives up on the whole ray
-    duct[prof] = 1;
+    const double tanth = tan(theta);
+    __syncthreads();                             // previous angle's seam reads are done
+    if (lane == WAVE - 1) { seam[wave][1] = tanth; seam[wave][2] = dtheta; }
+    const bool trapped = __syncthreads_or(trapped_here);
+    double tanthl = __shfl_up(tanth, 1, WAVE);
+    double dthl = __shfl_up(dtheta, 1, WAVE);
+    if (lane == 0 && wave > 0) { tanthl = seam[wave - 1][1]; dthl = seam[wave - 1][2]; }
+    double f = 0.0;
+    if (tid > 0) {
+      const double cthbar = ((1.0 / tanth) + (1.0 / tanthl)) * 0.5;
+      const double dtau = cthbar * (nprev - ni) / refbar;
+      const double dphi = (dtheta - dthl) + dtau;
+      const double sh = sin(dphi * 0.5);
+      double dsi = sqrt(dz * dz + 4.0 * r * rl * (sh * sh));
+      if (dtau != 0.0) {
+        const double dtaua = fabs(dtau);
+        dsi = dsi * (dtaua / (2.0 * sin(dtaua * 0.5)));
+      }
+      f = (dz != 0.0) ? dsi / dz : 0.0;
+    }
+    if (active) out[tid] = trapped ? (tid == 0 ? 0.0 : qnan) : f;     // pyrtlib gives up on the whole ray
+    if (trapped && tid == 0) duct[prof] = 1;
   }
 }
 
