@@ -2,7 +2,8 @@
 //
 // HIP only: there is no CPU fallback in this library.  Without a GPU mwrt_device_count()
 // returns 0 and mwrt_create() fails with MWRT_ERR_NO_DEVICE.
-#include "mwrt_kernels.hip.h"
+#define MWRT_HOST_TU 1      // this translation unit owns the non-template kernels
+#include "mwrt_inst.hip.h"
 
 #include <cmath>
 #include <cstdio>
@@ -175,20 +176,11 @@ void timing_end(mwrt_context* c, hipStream_t st) {
   if (c->timing) { (void)hipEventRecord(c->ev1[c->ev_count % TIMING_RING], st); c->ev_count++; }
 }
 
-template <int NFC, int MAXT, bool FULL>
-int launch_fused_inst(const FusedArgs& a, dim3 grid, dim3 block, size_t lds, hipStream_t st) {
-  auto k = k_tb_fused<NFC, (NFC == 14 ? 7 : 8), MAXT, FULL>;
-  HIP_TRY(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  hipLaunchKernelGGL(k, grid, block, lds, st, a);
-  return MWRT_OK;
-}
-
-template <int NFC>
-int launch_fused(mwrt_context* c, FusedArgs a, int64_t nprof, hipStream_t st, bool full) {
+int launch_fused(mwrt_context* c, int nfc, FusedArgs a, int64_t nprof, hipStream_t st, int variant) {
   const int threads = ((a.nlev + WAVE - 1) / WAVE) * WAVE;
-  const int nchunks = (a.nf + NFC - 1) / NFC;
+  const int nchunks = (a.nf + nfc - 1) / nfc;
   size_t lds = 0;
-  if (!plan_fused(c, NFC, a.nlev, a.nf, a.nang, &a.g, &lds))
+  if (!plan_fused(c, nfc, a.nlev, a.nf, a.nang, &a.g, &lds))
     return fail(MWRT_ERR_UNSUPPORTED, "LDS budget exceeded (nlev x nang too large)");
   dim3 grid((unsigned)nprof /* = nmodels x profiles */, (unsigned)nchunks), block(threads);
   // valid[] = 1 is written by the kernel itself when one workgroup owns the profile; with several
@@ -196,34 +188,30 @@ int launch_fused(mwrt_context* c, FusedArgs a, int64_t nprof, hipStream_t st, bo
   a.write_valid = nchunks == 1;
   if (!a.write_valid) HIP_TRY(hipMemsetAsync(a.valid, 1, (size_t)nprof, st));
   timing_begin(c, st);
-  int rc;
-  // FULL = the instantiation that also carries the by-product columns and the opt-in physics; plain TB
-  // requests (bench, the wrapper's batched call) run the lean TB-only instantiation
-  if (threads <= 256) rc = full ? launch_fused_inst<NFC, 256, true>(a, grid, block, lds, st)
-                                : launch_fused_inst<NFC, 256, false>(a, grid, block, lds, st);
-  // taller profiles: 512-thread workgroups get 256 VGPRs per lane (no scratch); only > 512 levels fall to the
-  // 1024-thread instantiation, whose 128-VGPR cap spills (profiles/r02_tall_profiles.txt)
-  else if (threads <= 512) rc = full ? launch_fused_inst<NFC, 512, true>(a, grid, block, lds, st)
-                                     : launch_fused_inst<NFC, 512, false>(a, grid, block, lds, st);
-  else rc = full ? launch_fused_inst<NFC, 1024, true>(a, grid, block, lds, st)
-                 : launch_fused_inst<NFC, 1024, false>(a, grid, block, lds, st);
+  hipError_t e;
+  switch (nfc) {                                    // one translation unit per chunk width (csrc/mwrt_inst.hip)
+    case 8: e = launch_fused_nfc8(a, grid, block, lds, st, variant); break;
+    case 14: e = launch_fused_nfc14(a, grid, block, lds, st, variant); break;
+    default: e = launch_fused_nfc16(a, grid, block, lds, st, variant); break;
+  }
   timing_end(c, st);
-  if (rc) return rc;
-  HIP_TRY(hipGetLastError());
+  HIP_TRY(e);
   return MWRT_OK;
 }
 
-template <int NFC>
-int launch_absorb(mwrt_context* c, AbsorbArgs a, int64_t nprof, hipStream_t st) {
+int launch_absorb(mwrt_context* c, int nfc, const AbsorbArgs& a, int64_t nprof, hipStream_t st) {
   const int threads = ((a.nlev + WAVE - 1) / WAVE) * WAVE;
-  const int nchunks = (a.nf + NFC - 1) / NFC;
+  const int nchunks = (a.nf + nfc - 1) / nfc;
   dim3 grid((unsigned)nprof, (unsigned)nchunks), block(threads);
   timing_begin(c, st);
-  if (threads <= 256) hipLaunchKernelGGL((k_absorb<NFC, 256>), grid, block, 0, st, a);
-  else if (threads <= 512) hipLaunchKernelGGL((k_absorb<NFC, 512>), grid, block, 0, st, a);
-  else hipLaunchKernelGGL((k_absorb<NFC, 1024>), grid, block, 0, st, a);
+  hipError_t e;
+  switch (nfc) {
+    case 8: e = launch_absorb_nfc8(a, grid, block, st); break;
+    case 14: e = launch_absorb_nfc14(a, grid, block, st); break;
+    default: e = launch_absorb_nfc16(a, grid, block, st); break;
+  }
   timing_end(c, st);
-  HIP_TRY(hipGetLastError());
+  HIP_TRY(e);
   return MWRT_OK;
 }
 
@@ -435,13 +423,9 @@ static int tb_launch(mwrt_context* c, int nmodels, const mwrt_model* const* ms, 
     a.amf = c->d_amf.as<double>();
     a.duct = c->d_duct.as<uint8_t>();
   }
-  const bool full = use_opt || (ex && (ex->tbatm || ex->tmr || ex->tauwet || ex->taudry || ex->taulay || ex->tauliq ||
-                                      ex->tauice));
-  switch (pick_nfc_fused(c, nlev, nf, nang)) {
-    case 8: return launch_fused<8>(c, a, rows, st, full);
-    case 14: return launch_fused<14>(c, a, rows, st, full);
-    default: return launch_fused<16>(c, a, rows, st, full);
-  }
+  const bool extras = ex && (ex->tbatm || ex->tmr || ex->tauwet || ex->taudry || ex->taulay || ex->tauliq || ex->tauice);
+  const int variant = extras ? FUSED_FULL : (use_opt ? FUSED_OPT : FUSED_TB_ONLY);
+  return launch_fused(c, pick_nfc_fused(c, nlev, nf, nang), a, rows, st, variant);
 }
 
 int mwrt_tb_batch_device(mwrt_context* c, const mwrt_model* m, int64_t nprof, int32_t nlev,
@@ -590,11 +574,7 @@ int mwrt_absorption_batch_device(mwrt_context* c, const mwrt_model* m, int64_t n
   AbsorbArgs a{};
   a.M = m->d_desc; a.p = d_p; a.t = d_t; a.rh = d_rh; a.frq = dev_frq;
   a.awet = d_awet; a.adry = d_adry; a.nlev = nlev; a.nf = nf;
-  switch (pick_nfc(nf)) {
-    case 8: return launch_absorb<8>(c, a, nprof, st);
-    case 14: return launch_absorb<14>(c, a, nprof, st);
-    default: return launch_absorb<16>(c, a, nprof, st);
-  }
+  return launch_absorb(c, pick_nfc(nf), a, nprof, st);
 }
 
 int mwrt_absorption_batch(mwrt_context* c, const mwrt_model* m, int64_t nprof, int32_t nlev,

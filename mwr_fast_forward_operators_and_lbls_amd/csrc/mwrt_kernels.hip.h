@@ -793,72 +793,70 @@ __device__ __forceinline__ double layer_value(double x1, double x0, bool& neg) {
 // ---------------------------------------------------------------------------------------------
 // Opt-in physics the reference leaves at pyrtlib's defaults: cloud liquid / ice
 // absorption (cloudy=True + init_cloudy) and spherical refracted ray tracing (ray_tracing=True).
-// Only the FULL instantiations of the fused kernel contain this code; the TB-only kernel is untouched.
+// Only the OPT instantiations of the fused kernel contain this code; the clear-sky kernels are untouched.
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ cplx clog_(cplx w) {       // principal complex logarithm
   return {0.5 * flog(__builtin_fma(w.re, w.re, w.im * w.im)), atan2(w.im, w.re)};
 }
 
-// RTEquation.cloudy_absorption + LiqAbsModel.liquid_water_absorption [EXT]: Np/km per level for NFC frequencies.
-// denl / deni in g m-3.  Skipped (all zeros) when no lane of the wave holds any cloud.
-template <int NFC>
-__device__ __forceinline__ void cloud_absorb(cmodel M, double tk, double denl, double deni, const double* sfq,
-                                             double (&aliq)[NFC], double (&aice)[NFC]) {
-#pragma unroll
-  for (int j = 0; j < NFC; ++j) { aliq[j] = 0.0; aice[j] = 0.0; }
-  const bool liq = denl > 0.0, ice = deni > 0.0;
-  if (!__any(liq || ice)) return;
-  // ice: (8.18645 / wavelength[cm]) * deni * 0.000959553 dB/km -> Np/km
-  const double kice = 8.18645 * 0.000959553 * (0.1 * 2.302585092994045684) / 29.9792458;
-  if (M->liq_mode == 0) {
-    // Liebe, Hufford & Manabe 1991 / MPM93 double Debye
+// RTEquation.cloudy_absorption + LiqAbsModel.liquid_water_absorption [EXT]: Np/km at one level.
+// The frequency-independent part of the liquid model is built once per level (CloudLevel), the per-frequency
+// part is a handful of complex operations; ice is (8.18645 / wavelength[cm]) * deni * 0.000959553 dB/km.
+struct CloudLevel {
+  int mode;                      // liq_mode of the model
+  double eps0;                   // static dielectric constant
+  // mode 0 (Liebe, Hufford & Manabe 1991 / MPM93 double Debye):  a = eps1, b = 1/fp, c = 1/fs
+  // mode 1 (Rosenkranz 2015: Patek 2009 static constant, Ellison 2007 Debye term, B-band term):
+  //         a = delta, b = sd, c = delta_B, z1 and 1/cnorm complex
+  double a, b, c;
+  cplx z1, icnorm;
+};
+constexpr double CLOUD_KICE = 8.18645 * 0.000959553 * (0.1 * 2.302585092994045684) / 29.9792458;
+
+__device__ __forceinline__ CloudLevel cloud_level(cmodel M, double tk) {
+  CloudLevel c{};
+  c.mode = M->liq_mode;
+  if (c.mode == 0) {
     const double theta1 = 1.0 - fdiv(300.0, tk);
-    const double eps0 = 77.66 - 103.3 * theta1;
-    const double eps1 = 0.0671 * eps0;
-    const double eps2 = 3.52;
+    c.eps0 = 77.66 - 103.3 * theta1;
+    c.a = 0.0671 * c.eps0;
     const double fp = (316.0 * theta1 + 146.4) * theta1 + 20.2;
-    const double fs = 39.8 * fp;
-    const double rfp = fdiv(1.0, fp), rfs = fdiv(1.0, fs);
-#pragma unroll
-    for (int j = 0; j < NFC; ++j) {
-      const double f = sfq[2 * j];
-      const cplx t1 = cdiv(cplx{eps0 - eps1, 0.0}, cplx{1.0, f * rfp});
-      const cplx t2 = cdiv(cplx{eps1 - eps2, 0.0}, cplx{1.0, f * rfs});
-      const cplx eps = {t1.re + t2.re + eps2, t1.im + t2.im};
-      const cplx re = cdiv(cplx{eps.re - 1.0, eps.im}, cplx{eps.re + 2.0, eps.im});
-      aliq[j] = liq ? -0.06286 * re.im * f * denl : 0.0;
-      aice[j] = ice ? kice * f * deni : 0.0;
-    }
+    c.b = fdiv(1.0, fp);
+    c.c = fdiv(1.0, 39.8 * fp);
   } else {
-    // Rosenkranz 2015: Patek 2009 static constant, Ellison 2007 Debye term, B-band term
     const double tc = tk - 273.15;
     const double lth = flog(fdiv(300.0, tk));
-    const double eps0 = -43.7527 * fexp(0.05 * lth) + 299.504 * fexp(1.47 * lth) - 399.364 * fexp(2.11 * lth) +
-                        221.327 * fexp(2.31 * lth);
-    const double delta = 80.69715 * fexp(-tc * (1.0 / 226.45));
-    const double sd = 1164.023 * fexp(fdiv(-651.4728, tc + 133.07));
-    const double deltab = 4.008724 * fexp(-tc * (1.0 / 103.05));
-    const double hdelta = 0.5 * deltab;
+    c.eps0 = -43.7527 * fexp(0.05 * lth) + 299.504 * fexp(1.47 * lth) - 399.364 * fexp(2.11 * lth) + 221.327 * fexp(2.31 * lth);
+    c.a = 80.69715 * fexp(-tc * (1.0 / 226.45));
+    c.b = 1164.023 * fexp(fdiv(-651.4728, tc + 133.07));
+    c.c = 4.008724 * fexp(-tc * (1.0 / 103.05));
     const double f1 = 10.46012 + tc * (0.1454962 + tc * (0.063267156 + tc * 0.00093786645));
-    const cplx z1 = {-0.75 * f1, f1};
-    const cplx z2 = {-4500.0, 2000.0};
-    const cplx cnorm = clog_(cdiv(z2, z1));
-    const cplx icnorm = crecip(cnorm);                       // 1/cnorm; 1/conj(cnorm) is its conjugate
-#pragma unroll
-    for (int j = 0; j < NFC; ++j) {
-      const double f = sfq[2 * j];
-      const cplx z = {0.0, f};
-      const cplx kap0 = cdiv(cplx{0.0, -delta * f}, cplx{sd, f});              // -delta z / (sd + z)
-      const cplx lp = clog_(cdiv(cplx{z.re - z2.re, z.im - z2.im}, cplx{z.re - z1.re, z.im - z1.im}));
-      const cplx lj = clog_(cdiv(cplx{z.re - z2.re, z.im + z2.im}, cplx{z.re - z1.re, z.im + z1.im}));
-      const cplx chip = cmul(cplx{hdelta * lp.re, hdelta * lp.im}, icnorm);
-      const cplx chij = cmul(cplx{hdelta * lj.re, hdelta * lj.im}, cplx{icnorm.re, -icnorm.im});
-      const cplx eps = {eps0 + (kap0.re + (chip.re + chij.re - deltab)), kap0.im + (chip.im + chij.im)};
-      const cplx re = cdiv(cplx{eps.re - 1.0, eps.im}, cplx{eps.re + 2.0, eps.im});
-      aliq[j] = liq ? -0.06286 * re.im * f * denl : 0.0;
-      aice[j] = ice ? kice * f * deni : 0.0;
-    }
+    c.z1 = cplx{-0.75 * f1, f1};
+    c.icnorm = crecip(clog_(cdiv(cplx{-4500.0, 2000.0}, c.z1)));      // 1/cnorm; 1/conj(cnorm) is its conjugate
   }
+  return c;
+}
+
+// liquid absorption for water content `denl` [g m-3] at frequency f [GHz]
+__device__ __forceinline__ double liquid_abs(const CloudLevel& c, double f, double denl) {
+  cplx eps;
+  if (c.mode == 0) {
+    const double eps2 = 3.52;
+    const cplx t1 = cdiv(cplx{c.eps0 - c.a, 0.0}, cplx{1.0, f * c.b});
+    const cplx t2 = cdiv(cplx{c.a - eps2, 0.0}, cplx{1.0, f * c.c});
+    eps = cplx{t1.re + t2.re + eps2, t1.im + t2.im};
+  } else {
+    const cplx z2 = {-4500.0, 2000.0};
+    const double hdelta = 0.5 * c.c;
+    const cplx kap0 = cdiv(cplx{0.0, -c.a * f}, cplx{c.b, f});                   // -delta z / (sd + z), z = i f
+    const cplx lp = clog_(cdiv(cplx{-z2.re, f - z2.im}, cplx{-c.z1.re, f - c.z1.im}));
+    const cplx lj = clog_(cdiv(cplx{-z2.re, f + z2.im}, cplx{-c.z1.re, f + c.z1.im}));
+    const cplx chip = cmul(cplx{hdelta * lp.re, hdelta * lp.im}, c.icnorm);
+    const cplx chij = cmul(cplx{hdelta * lj.re, hdelta * lj.im}, cplx{c.icnorm.re, -c.icnorm.im});
+    eps = cplx{c.eps0 + (kap0.re + (chip.re + chij.re - c.c)), kap0.im + (chip.im + chij.im)};
+  }
+  const cplx re = cdiv(cplx{eps.re - 1.0, eps.im}, cplx{eps.re + 2.0, eps.im});
+  return -0.06286 * re.im * f * denl;
 }
 
 // RTEquation.refractivity [EXT] (Thayer 1974): refractive index at one level
@@ -885,6 +883,7 @@ __device__ __forceinline__ double thayer_refindex(double p, double tk, double e)
 // reference's own order; agreement ~1e-12 relative in ds).  A trapped ray (ducting: argth <= 0 at any level)
 // gives NaN factors for that angle and duct[profile] = 1.  libm calls (asin, tan, ...): ~3 % of the opt-in
 // path's arithmetic, not tuned further.
+#ifdef MWRT_HOST_TU      // non-template kernels live in ONE translation unit (csrc/mwrt.hip)
 constexpr double EARTH_RADIUS_KM = 6370.949;
 __global__ void __launch_bounds__(1024)
 k_ray_paths(const double* __restrict__ z, const double* __restrict__ p, const double* __restrict__ t,
@@ -971,6 +970,8 @@ k_ray_paths(const double* __restrict__ z, const double* __restrict__ p, const do
   }
 }
 
+#endif  // MWRT_HOST_TU
+
 // ---------------------------------------------------------------------------------------------
 // fused kernel: profile in -> TB out
 // ---------------------------------------------------------------------------------------------
@@ -990,7 +991,7 @@ struct FusedArgs {
   int nlev, nf, nang;
   int write_valid;         // 1: this launch has one workgroup per profile and sets valid = 1 itself
   LaunchGeom g;
-  // by-products and opt-in physics (read by the FULL instantiations only; null / 0 otherwise)
+  // by-products and opt-in physics (read by the OPT / EXTRAS instantiations only; null / 0 otherwise)
   const double* denliq; const double* denice;   // [nprof][nlev] g m-3, either may be null
   const double* amf;       // [nprof][nang][nlev] ray-traced path factor ds/dz, or null (plane-parallel)
   const uint8_t* duct;     // [nprof] 1: a ray of this profile was trapped (valid = 3)
@@ -1020,11 +1021,13 @@ __device__ __forceinline__ void blank_outputs(const FusedArgs& A, int64_t prof, 
 // NFK = frequencies per K2 pass (rows of tau / B kept in LDS at a time): NFC = NPASS * NFK.
 // Keeping only NFK rows resident holds the workgroup under 40 KB of LDS, so FOUR 192-thread
 // workgroups (12 waves = 3 per SIMD) fit a CU and a 1000-profile batch is one resident round.
+// (the cloud / ray-tracing TB variant lands one register above the 3-waves-per-SIMD step on its own: it is
+// asked for 3 waves explicitly)
 #ifndef MWRT_MIN_WAVES
 #define MWRT_MIN_WAVES 1
 #endif
-template <int NFC, int NFK, int MAXT, bool FULL = false>
-__global__ void __launch_bounds__(MAXT, (MAXT <= 256 ? MWRT_MIN_WAVES : 1))
+template <int NFC, int NFK, int MAXT, bool OPT = false, bool EXTRAS = false>
+__global__ void __launch_bounds__(MAXT, (MAXT <= 256 ? ((OPT && !EXTRAS) ? 3 : MWRT_MIN_WAVES) : 1))
 k_tb_fused(const FusedArgs A) {
   static_assert(NFC % NFK == 0, "NFC must be a multiple of NFK");
   constexpr int NPASS = NFC / NFK;
@@ -1073,7 +1076,7 @@ k_tb_fused(const FusedArgs A) {
   const double zi = A.z[off], pi = A.p[off], ti = A.t[off], rhi = A.rh[off];
   if (active && (isnan(zi) || isnan(pi) || isnan(ti) || isnan(rhi))) atomicOr(&s_flag, 1);
   double denl = 0.0, deni = 0.0;
-  if constexpr (FULL) {
+  if constexpr (OPT) {
     if (A.denliq) denl = A.denliq[off];
     if (A.denice) deni = A.denice[off];
     if (active && (isnan(denl) || isnan(deni))) atomicOr(&s_flag, 1);
@@ -1100,7 +1103,9 @@ k_tb_fused(const FusedArgs A) {
     for (int j = 0; j < NFC; ++j) { edge[wave * 2 * NFC + j] = awet[j]; edge[wave * 2 * NFC + NFC + j] = adry[j]; }
   }
   __syncthreads();
-  double tw[NFC], td[NFC];
+  // Wet and dry rows are kept apart only where the opacity columns are wanted (EXTRAS); otherwise td[] holds
+  // the layer total (wet + dry, then + ice + liquid) and tw[] is never materialised: 28 registers fewer.
+  double tw[EXTRAS ? NFC : 1], td[NFC];
   bool neg = false;
   {
     const double z0 = A.z[pin * nlev];        // execute() works in height above the antenna
@@ -1112,36 +1117,50 @@ k_tb_fused(const FusedArgs A) {
       double pw = __shfl_up(awet[j], 1, WAVE);
       double pd = __shfl_up(adry[j], 1, WAVE);
       if (seam) { pw = edge[(wave - 1) * 2 * NFC + j]; pd = edge[(wave - 1) * 2 * NFC + NFC + j]; }
-      tw[j] = has_prev ? layer_value(awet[j], pw, neg) * dz : 0.0;
-      td[j] = has_prev ? layer_value(adry[j], pd, neg) * dz : 0.0;
+      const double twj = has_prev ? layer_value(awet[j], pw, neg) * dz : 0.0;
+      const double tdj = has_prev ? layer_value(adry[j], pd, neg) * dz : 0.0;
+      if constexpr (EXTRAS) { tw[j] = twj; td[j] = tdj; }
+      else td[j] = twj + tdj;
     }
   }
   // cloud liquid / ice (opt-in): same layer rule with zeroflg = False; tau = ((wet + dry) + ice) + liquid
-  double tl[FULL ? NFC : 1], tci[FULL ? NFC : 1];
-  if constexpr (FULL) {
+  // (kept as separate arrays only where the opacity columns are wanted; otherwise folded into the dry row)
+  constexpr bool CLOUD_ROWS = OPT && EXTRAS;
+  double tl[CLOUD_ROWS ? NFC : 1], tci[CLOUD_ROWS ? NFC : 1];
+  if constexpr (OPT) {
 #pragma unroll
-    for (int j = 0; j < NFC; ++j) { tl[j] = 0.0; tci[j] = 0.0; }
-    if (A.denliq || A.denice) {
-      double aliq[NFC], aice[NFC];
-      cloud_absorb<NFC>(M, ti, denl, deni, sfq, aliq, aice);
-      __syncthreads();                          // the wet / dry seam rows have been read
-      if (lane == WAVE - 1) {
+    for (int j = 0; j < (CLOUD_ROWS ? NFC : 1); ++j) { tl[j] = 0.0; tci[j] = 0.0; }
+    // Skipped when the profile holds no cloud at all (workgroup vote).  The liquid absorption of every level goes
+    // through the (still unused) tau / Planck rows of LDS, [frequency][level], so each lane reads its own and its
+    // lower neighbour's value: no crossbar, no wave seams, and the per-level model state dies before the layer loop.
+    const bool cloud_here = active && (denl > 0.0 || deni > 0.0);
+    if ((A.denliq || A.denice) && __syncthreads_or(cloud_here)) {
+      auto row = [&](int j) -> double* { return (j < NFK ? tau + (size_t)j * ld : bof + (size_t)(j - NFK) * ld); };
+      {
+        const CloudLevel cl = cloud_level(M, ti);
+        if (active) {
 #pragma unroll
-        for (int j = 0; j < NFC; ++j) { edge[wave * 2 * NFC + j] = aliq[j]; edge[wave * 2 * NFC + NFC + j] = aice[j]; }
+          for (int j = 0; j < NFC; ++j) row(j)[tid] = (denl > 0.0) ? liquid_abs(cl, sfq[2 * j], denl) : 0.0;
+        }
       }
       __syncthreads();
+      const bool has_below = active && tid > 0;
+      const double deni_prev = (has_below && A.denice) ? A.denice[off - 1] : 0.0;
       const double z0 = A.z[pin * nlev];
-      const double dz = (active && tid > 0) ? ((zi - z0) - (A.z[off - 1] - z0)) : 0.0;
-      const bool seam = (lane == 0) && (wave > 0);
-      const bool has_prev = active && tid > 0;
+      const double dz = has_below ? ((zi - z0) - (A.z[off - 1] - z0)) : 0.0;
 #pragma unroll
       for (int j = 0; j < NFC; ++j) {
-        double pl = __shfl_up(aliq[j], 1, WAVE);
-        double pc = __shfl_up(aice[j], 1, WAVE);
-        if (seam) { pl = edge[(wave - 1) * 2 * NFC + j]; pc = edge[(wave - 1) * 2 * NFC + NFC + j]; }
-        tl[j] = has_prev ? layer_value<false>(aliq[j], pl, neg) * dz : 0.0;
-        tci[j] = has_prev ? layer_value<false>(aice[j], pc, neg) * dz : 0.0;
+        const double f = sfq[2 * j];
+        const double al = active ? row(j)[tid] : 0.0;
+        const double pl = has_below ? row(j)[tid - 1] : 0.0;
+        const double ai = (deni > 0.0) ? CLOUD_KICE * f * deni : 0.0;
+        const double pc = (deni_prev > 0.0) ? CLOUD_KICE * f * deni_prev : 0.0;
+        const double tlj = has_below ? layer_value<false>(al, pl, neg) * dz : 0.0;
+        const double tij = has_below ? layer_value<false>(ai, pc, neg) * dz : 0.0;
+        if constexpr (CLOUD_ROWS) { tl[j] = tlj; tci[j] = tij; }
+        else td[j] = (td[j] + tij) + tlj;
       }
+      __syncthreads();                          // the rows are about to be refilled with tau / B
     }
   }
   if (neg) atomicOr(&s_flag, 2);
@@ -1152,14 +1171,18 @@ k_tb_fused(const FusedArgs A) {
     return;
   }
   const double hk = 1e9 * M->planck_h / M->boltzmann_k;
-  // The TB-only instantiation (FULL = false) carries none of the by-product code: the compiler would
+  // The TB-only instantiation (EXTRAS = false) carries none of the by-product code: the compiler would
   // otherwise evaluate tbatm / tmr speculatively and keep the opacity sums' registers alive.
   bool want_tau = false;
-  if constexpr (FULL) {
+  if constexpr (EXTRAS) {
     if (A.taulay && active) {
 #pragma unroll
       for (int j = 0; j < NFC; ++j)
-        if (j < nfc) A.taulay[(prof * A.nf + jbase + j) * nlev + tid] = ((tw[j] + td[j]) + tci[j]) + tl[j];
+        if (j < nfc) {
+          double tz = tw[j] + td[j];
+          if constexpr (CLOUD_ROWS) tz = (tz + tci[j]) + tl[j];
+          A.taulay[(prof * A.nf + jbase + j) * nlev + tid] = tz;
+        }
     }
     want_tau = (A.tauwet != nullptr) || (A.taudry != nullptr) || (A.tauliq != nullptr) || (A.tauice != nullptr);
   }
@@ -1176,27 +1199,32 @@ k_tb_fused(const FusedArgs A) {
 #pragma unroll
       for (int jj = 0; jj < NFK; ++jj) {
         const int j = h * NFK + jj;
-        double tz = tw[j] + td[j];
-        if constexpr (FULL) tz = (tz + tci[j]) + tl[j];
+        double tz = td[j];
+        if constexpr (EXTRAS) tz = tw[j] + td[j];
+        if constexpr (CLOUD_ROWS) tz = (tz + tci[j]) + tl[j];
         tau[jj * ld + tid] = tz;
         bof[jj * ld + tid] = planck_b(sfq[2 * j] * hkt);
       }
     }
     // optional zenith opacity sums (tauwet / taudry columns); deterministic order
-    double swet[FULL ? NFK : 1], sdry[FULL ? NFK : 1], sliq[FULL ? NFK : 1], sice[FULL ? NFK : 1];
-    const bool rays = FULL && A.amf != nullptr;
-    if constexpr (FULL) {
+    double swet[EXTRAS ? NFK : 1], sdry[EXTRAS ? NFK : 1], sliq[EXTRAS ? NFK : 1], sice[EXTRAS ? NFK : 1];
+    const bool rays = OPT && A.amf != nullptr;
+    if constexpr (EXTRAS) {
       if (want_tau && !rays) {
 #pragma unroll
         for (int jj = 0; jj < NFK; ++jj) {
           swet[jj] = block_sum(tw[h * NFK + jj], scratch, tid, nthreads);
           sdry[jj] = block_sum(td[h * NFK + jj], scratch, tid, nthreads);
-          sliq[jj] = block_sum(tl[h * NFK + jj], scratch, tid, nthreads);
-          sice[jj] = block_sum(tci[h * NFK + jj], scratch, tid, nthreads);
+          if constexpr (OPT) {
+            sliq[jj] = block_sum(tl[h * NFK + jj], scratch, tid, nthreads);
+            sice[jj] = block_sum(tci[h * NFK + jj], scratch, tid, nthreads);
+          } else {
+            sliq[jj] = 0.0; sice[jj] = 0.0;
+          }
         }
       }
     }
-    if constexpr (FULL) {
+    if constexpr (EXTRAS && OPT) {
       if (want_tau && rays) {
         // ray-traced paths: the opacity columns are sums of layer value x path factor, one species at a
         // time through the tau rows (the DataFrame path of a single execute(); not a throughput path)
@@ -1245,11 +1273,11 @@ k_tb_fused(const FusedArgs A) {
       const double* tj = tau + jj * ld;
       const double* bj = bof + jj * ld;
       const double* fr = nullptr;
-      if constexpr (FULL) fr = A.amf ? A.amf + (pin * nang + a) * nlev : nullptr;
+      if constexpr (OPT) fr = A.amf ? A.amf + (pin * nang + a) * nlev : nullptr;
       double T = 1.0, B = 0.0, S = 0.0;
       double bprev = (lo < nlev) ? bj[lo - 1] : 0.0;
       for (int i = lo; i < hi; ++i) {
-        const double tl = tj[i] * ((FULL && fr) ? fr[i] : am);
+        const double tl = tj[i] * ((OPT && fr) ? fr[i] : am);
         const double E = __all(fabs(tl) <= EXP_SMALL_X) ? fexp_small(-tl) : fexp(-tl);
         const double bi = bj[i];
         const double lay = fdiv1(__builtin_fma(bi, E, bprev), 1.0 + E);
@@ -1278,13 +1306,13 @@ k_tb_fused(const FusedArgs A) {
         const double ex = fexp(-S);
         const double bbg = fdiv(1.0, fexp(fdiv(hvk, M->t_cosmic)) - 1.0);
         boftotl = __builtin_fma(bbg, ex, B);
-        boftmr = FULL ? fdiv(B, 1.0 - ex) : 0.0;
+        boftmr = EXTRAS ? fdiv(B, 1.0 - ex) : 0.0;
       } else {
         boftotl = B; boftmr = B;
       }
       const int64_t o = (prof * nang + a) * A.nf + jbase + j;
       A.tb[o] = fdiv(hvk, flog(1.0 + fdiv(1.0, boftotl)));
-      if constexpr (FULL) {
+      if constexpr (EXTRAS) {
         if (A.tbatm) A.tbatm[o] = fdiv(hvk, flog(1.0 + fdiv(1.0, B)));
         if (A.tmr) A.tmr[o] = fdiv(hvk, flog(1.0 + fdiv(1.0, boftmr)));
         if (want_tau && !rays) {
@@ -1300,7 +1328,7 @@ k_tb_fused(const FusedArgs A) {
       }
     }
   }
-  if constexpr (FULL) {
+  if constexpr (OPT) {
     // a trapped ray (ducting) leaves its angle NaN and marks the profile 3
     if (A.duct && A.duct[pin]) { if (tid == 0) A.valid[prof] = 3; return; }
   }
@@ -1363,6 +1391,7 @@ k_absorb(const AbsorbArgs A) {
   }
 }
 
+#ifdef MWRT_HOST_TU
 // diagnostic: the local exp / log / division helpers on caller-supplied arguments (mwrt_selftest_math)
 __global__ void k_selftest_math(const double* x, const double* y, double* out_exp, double* out_log, double* out_div,
                                 double* out_div1, int n) {
@@ -1373,5 +1402,7 @@ __global__ void k_selftest_math(const double* x, const double* y, double* out_ex
   out_div[i] = fdiv(x[i], y[i]);
   out_div1[i] = fdiv1(x[i], y[i]);
 }
+
+#endif  // MWRT_HOST_TU
 
 }  // namespace mwrt
