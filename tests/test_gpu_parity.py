@@ -884,3 +884,22 @@ def test_opt_device_entry(gpu_ctx):
                                 d_denliq=dl.data_ptr(), d_denice=di.data_ptr(), ray_tracing=True)
         got = out.cpu().numpy()
     assert np.array_equal(got, host) and np.array_equal(val.cpu().numpy(), hv)
+
+
+@pytest.mark.parametrize("name", ["R98", "R24"])
+def test_opt_in_golden_vectors(gpu_ctx, name):
+    """The committed cloud / ray-tracing vectors (tests/golden/lbl_golden_opt_v1.npz) through the C ABI."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "lbl_golden_opt_v1.npz")
+    with np.load(path, allow_pickle=False) as f:
+        g = {k: f[k] for k in f.files}
+    for tag, cloud, rays in (("cloud", True, False), ("rays", False, True), ("both", True, True)):
+        tb, valid, ex = gpu_ctx.tb_batch(name, g["z"], g["p"], g["t"], g["rh"], g["frq"], g["ang"], extras=True,
+                                         denliq=g["lwc"] if cloud else None, denice=g["iwc"] if cloud else None,
+                                         ray_tracing=rays)
+        assert (valid == 1).all()
+        assert np.abs(tb - g[f"{name}_{tag}_tbtotal"]).max() <= TOL_K, tag
+        for k in ("tauwet", "taudry", "tauliq", "tauice"):
+            assert np.allclose(ex[k], g[f"{name}_{tag}_{k}"], rtol=1e-9, atol=1e-14), (tag, k)
+        tb2, _ = gpu_ctx.tb_batch(name, g["z"], g["p"], g["t"], g["rh"], g["frq"], g["ang"],
+                                  denliq=g["lwc"] if cloud else None, denice=g["iwc"] if cloud else None, ray_tracing=rays)
+        assert np.abs(tb2 - g[f"{name}_{tag}_tbtotal"]).max() <= TOL_K, tag      # TB-only OPT instantiation
