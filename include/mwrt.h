@@ -218,6 +218,20 @@ int mwrt_absorption_batch_device(mwrt_context* ctx, const mwrt_model* model,
                                  int32_t nf, const double* frq_ghz,
                                  double* d_awet_out, double* d_adry_out, void* stream);
 
+/* The second half of execute() on its own: layer optical depths (exponential_integration, zeroflg = True) +
+ * downwelling Planck-space RTE (planck, bright) from absorption coefficients ALREADY in HBM, laid out as
+ * mwrt_absorption_batch_device writes them (awet, adry [nprof][nf][nlev], Np/km).  Together the two calls are
+ * the K1 -> alpha -> K2 two-kernel form of the fine-grid configuration (BASELINE configs[4]: alpha is 3.6 GB
+ * per GPU, written once and read once); it is also the entry for callers who bring their own absorption.
+ * `model` supplies the RTE constants only (t_cosmic, h, k).  DEVICE buffers; valid as for mwrt_tb_batch
+ * (0 also for a NaN absorption coefficient). */
+int mwrt_tb_from_absorption_device(mwrt_context* ctx, const mwrt_model* model,
+                                   int64_t nprof, int32_t nlev,
+                                   const double* d_z_km, const double* d_t_k,
+                                   int32_t nf, const double* frq_ghz, int32_t nang, const double* elev_deg,
+                                   const double* d_awet, const double* d_adry,
+                                   double* d_tb_out, uint8_t* d_valid_out, void* stream);
+
 /* Diagnostic: evaluates the kernels' own exp / log / division helpers (fexp, flog, fdiv, fdiv1) on
  * host arrays x[n], y_pos[n] (y > 0), so their accuracy can be checked against libm. */
 int mwrt_selftest_math(mwrt_context* ctx, int32_t n, const double* x, const double* y_pos,

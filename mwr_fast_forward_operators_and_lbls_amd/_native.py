@@ -65,6 +65,8 @@ SIGNATURES = {
     "mwrt_tb_batch_opt_device": (ctypes.c_int, [_vp, _vp, _i64, _i32, _vp, _vp, _vp, _vp, _i32, _vp, _i32, _vp,
                                                 _vp, _vp, ctypes.POINTER(MwrtTbExtras), ctypes.POINTER(MwrtTbOptions),
                                                 _vp]),
+    "mwrt_tb_from_absorption_device": (ctypes.c_int, [_vp, _vp, _i64, _i32, _vp, _vp, _i32, _vp, _i32, _vp, _vp, _vp,
+                                                      _vp, _vp, _vp]),
     "mwrt_tb_batch_multi": (ctypes.c_int, [_vp, _i32, ctypes.POINTER(_vp), _i64, _i32, _vp, _vp, _vp, _vp, _i32, _vp,
                                            _i32, _vp, _vp, _vp]),
     "mwrt_tb_batch_multi_device": (ctypes.c_int, [_vp, _i32, ctypes.POINTER(_vp), _i64, _i32, _vp, _vp, _vp, _vp, _i32,
@@ -330,6 +332,16 @@ class Context:
             frq.size, _ptr(frq), elev.size, _ptr(elev), _ptr(d_tb), _ptr(d_valid),
             ctypes.byref(extras) if extras is not None else None, ctypes.byref(opts),
             _stream(stream)), "mwrt_tb_batch_opt_device")
+
+    @_serialised
+    def tb_from_absorption_device(self, model, nprof, nlev, d_z, d_t, frq, elev, d_awet, d_adry, d_tb, d_valid, stream=None):
+        """Layer integration + RTE from absorption coefficients already in HBM ([nprof][nf][nlev], as
+        absorption_batch_device writes them): the K2 half of the K1 -> alpha -> K2 two-kernel form."""
+        frq, elev = _f64(frq).ravel(), _f64(elev).ravel()
+        self._check(self._lib.mwrt_tb_from_absorption_device(
+            self._handle, self.model(model), int(nprof), int(nlev), _ptr(d_z), _ptr(d_t), frq.size, _ptr(frq),
+            elev.size, _ptr(elev), _ptr(d_awet), _ptr(d_adry), _ptr(d_tb), _ptr(d_valid), _stream(stream)),
+            "mwrt_tb_from_absorption_device")
 
     @_serialised
     def absorption_batch_device(self, model, nprof, nlev, d_p, d_t, d_rh, frq, d_awet, d_adry, stream=None):

@@ -337,7 +337,7 @@ static int tb_launch(mwrt_context* c, int nmodels, const mwrt_model* const* ms, 
                      const double* d_z, const double* d_p, const double* d_t, const double* d_rh,
                      int32_t nf, const double* frq, int32_t nang, const double* elev,
                      double* d_tb, uint8_t* d_valid, const mwrt_tb_extras* ex, void* stream,
-                     const mwrt_tb_options* opt = nullptr) {
+                     const mwrt_tb_options* opt = nullptr, const double* d_awet = nullptr, const double* d_adry = nullptr) {
   if (nmodels < 1 || nmodels > MAX_MULTI || !ms) return fail(MWRT_ERR_INVALID_ARGUMENT, "nmodels must be 1..8");
   const bool cloudy = opt && (opt->denliq || opt->denice);
   const bool rays = opt && opt->ray_tracing != 0;
@@ -347,7 +347,8 @@ static int tb_launch(mwrt_context* c, int nmodels, const mwrt_model* const* ms, 
     if (rc) return rc;
   }
   if (nang < 1 || nang > MWRT_MAX_ANGLES) return fail(MWRT_ERR_INVALID_ARGUMENT, "nang out of range");
-  if (!d_z || !d_p || !d_t || !d_rh || !frq || !elev || !d_tb || !d_valid)
+  const bool from_alpha = d_awet != nullptr;
+  if (!d_z || !d_t || !frq || !elev || !d_tb || !d_valid || (!from_alpha && (!d_p || !d_rh)) || (from_alpha && !d_adry))
     return fail(MWRT_ERR_INVALID_ARGUMENT, "null buffer");
   const int64_t rows = nprof * nmodels;
   if (rows > 2147483647LL) return fail(MWRT_ERR_UNSUPPORTED, "nmodels x nprof exceeds grid limit");
@@ -424,7 +425,13 @@ static int tb_launch(mwrt_context* c, int nmodels, const mwrt_model* const* ms, 
     a.duct = c->d_duct.as<uint8_t>();
   }
   const bool extras = ex && (ex->tbatm || ex->tmr || ex->tauwet || ex->taudry || ex->taulay || ex->tauliq || ex->tauice);
-  const int variant = extras ? FUSED_FULL : (use_opt ? FUSED_OPT : FUSED_TB_ONLY);
+  int variant = extras ? FUSED_FULL : (use_opt ? FUSED_OPT : FUSED_TB_ONLY);
+  if (from_alpha) {
+    if (extras || use_opt || nmodels != 1)
+      return fail(MWRT_ERR_UNSUPPORTED, "RTE from absorption: one model, no extras, no options");
+    a.awet_in = d_awet; a.adry_in = d_adry;
+    variant = FUSED_FROM_ALPHA;
+  }
   return launch_fused(c, pick_nfc_fused(c, nlev, nf, nang), a, rows, st, variant);
 }
 
@@ -443,6 +450,16 @@ int mwrt_tb_batch_opt_device(mwrt_context* c, const mwrt_model* m, int64_t nprof
                              void* stream) {
   if (!c || !m) return fail(MWRT_ERR_INVALID_ARGUMENT, "null context or model");
   return tb_launch(c, 1, &m, nprof, nlev, d_z, d_p, d_t, d_rh, nf, frq, nang, elev, d_tb, d_valid, ex, stream, opt);
+}
+
+int mwrt_tb_from_absorption_device(mwrt_context* c, const mwrt_model* m, int64_t nprof, int32_t nlev,
+                                   const double* d_z, const double* d_t, int32_t nf, const double* frq, int32_t nang,
+                                   const double* elev, const double* d_awet, const double* d_adry,
+                                   double* d_tb, uint8_t* d_valid, void* stream) {
+  if (!c || !m) return fail(MWRT_ERR_INVALID_ARGUMENT, "null context or model");
+  if (!d_awet || !d_adry) return fail(MWRT_ERR_INVALID_ARGUMENT, "null buffer");
+  return tb_launch(c, 1, &m, nprof, nlev, d_z, nullptr, d_t, nullptr, nf, frq, nang, elev, d_tb, d_valid, nullptr, stream,
+                   nullptr, d_awet, d_adry);
 }
 
 int mwrt_tb_batch_multi_device(mwrt_context* c, int32_t nmodels, const mwrt_model* const* models, int64_t nprof,

@@ -13,9 +13,9 @@ namespace {
 constexpr int NFC = MWRT_INST_NFC;
 constexpr int NFK = (NFC == 14) ? 7 : 8;
 
-template <int MAXT, bool OPT, bool EXTRAS>
+template <int MAXT, bool OPT, bool EXTRAS, bool ALPHA>
 hipError_t launch_one(const FusedArgs& a, dim3 grid, dim3 block, size_t lds, hipStream_t st) {
-  auto k = k_tb_fused<NFC, NFK, MAXT, OPT, EXTRAS>;
+  auto k = k_tb_fused<NFC, NFK, MAXT, OPT, EXTRAS, ALPHA>;
   hipError_t e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(k, grid, block, lds, st, a);
@@ -25,11 +25,11 @@ hipError_t launch_one(const FusedArgs& a, dim3 grid, dim3 block, size_t lds, hip
 // workgroup size class: 256 threads up to 256 levels; 512 threads get 256 VGPRs per lane (no scratch);
 // only > 512 levels fall to the 1024-thread instantiation, whose 128-VGPR cap spills
 // (profiles/r02_tall_profiles.txt)
-template <bool OPT, bool EXTRAS>
+template <bool OPT, bool EXTRAS, bool ALPHA = false>
 hipError_t launch_by_size(const FusedArgs& a, dim3 grid, dim3 block, size_t lds, hipStream_t st) {
-  if (block.x <= 256) return launch_one<256, OPT, EXTRAS>(a, grid, block, lds, st);
-  if (block.x <= 512) return launch_one<512, OPT, EXTRAS>(a, grid, block, lds, st);
-  return launch_one<1024, OPT, EXTRAS>(a, grid, block, lds, st);
+  if (block.x <= 256) return launch_one<256, OPT, EXTRAS, ALPHA>(a, grid, block, lds, st);
+  if (block.x <= 512) return launch_one<512, OPT, EXTRAS, ALPHA>(a, grid, block, lds, st);
+  return launch_one<1024, OPT, EXTRAS, ALPHA>(a, grid, block, lds, st);
 }
 
 }  // namespace
@@ -42,6 +42,7 @@ hipError_t MWRT_CAT(launch_fused_nfc, MWRT_INST_NFC)(const FusedArgs& a, dim3 gr
   switch (variant) {
     case FUSED_TB_ONLY: return launch_by_size<false, false>(a, grid, block, lds, st);
     case FUSED_OPT: return launch_by_size<true, false>(a, grid, block, lds, st);
+    case FUSED_FROM_ALPHA: return launch_by_size<false, false, true>(a, grid, block, lds, st);
     default: return launch_by_size<true, true>(a, grid, block, lds, st);
   }
 }

@@ -12,7 +12,8 @@ namespace mwrt {
 enum FusedVariant {
   FUSED_TB_ONLY = 0,   // clear sky, plane-parallel, TB only: the throughput path (bench, the wrapper's batched call)
   FUSED_OPT = 1,       // + cloud liquid / ice and ray-traced paths (mwrt_tb_options), TB only
-  FUSED_FULL = 2       // + the other DataFrame columns and layer optical depths (mwrt_tb_extras)
+  FUSED_FULL = 2,      // + the other DataFrame columns and layer optical depths (mwrt_tb_extras)
+  FUSED_FROM_ALPHA = 3 // layer integration + RTE from absorption coefficients already in HBM (no K1), TB only
 };
 
 #define MWRT_DECLARE_INST(N)                                                                                         \

@@ -996,6 +996,8 @@ struct FusedArgs {
   const double* amf;       // [nprof][nang][nlev] ray-traced path factor ds/dz, or null (plane-parallel)
   const uint8_t* duct;     // [nprof] 1: a ray of this profile was trapped (valid = 3)
   double* tauliq; double* tauice;               // optional [nprof][nang][nf]
+  // ALPHA instantiation (RTE from materialised absorption): awet, adry [nprof][nf][nlev] as k_absorb writes them
+  const double* awet_in; const double* adry_in;
 };
 
 // NaN / negative-absorption exit: every output of this (profile, chunk) becomes NaN
@@ -1026,7 +1028,10 @@ __device__ __forceinline__ void blank_outputs(const FusedArgs& A, int64_t prof, 
 #ifndef MWRT_MIN_WAVES
 #define MWRT_MIN_WAVES 1
 #endif
-template <int NFC, int NFK, int MAXT, bool OPT = false, bool EXTRAS = false>
+// ALPHA = the K2 half alone: absorption coefficients are READ from HBM (what k_absorb wrote) instead of
+// evaluated -- the two-kernel K1 -> alpha -> K2 form of the fine-grid configuration, and the entry for callers
+// who bring their own absorption.
+template <int NFC, int NFK, int MAXT, bool OPT = false, bool EXTRAS = false, bool ALPHA = false>
 __global__ void __launch_bounds__(MAXT, (MAXT <= 256 ? ((OPT && !EXTRAS) ? 3 : MWRT_MIN_WAVES) : 1))
 k_tb_fused(const FusedArgs A) {
   static_assert(NFC % NFK == 0, "NFC must be a multiple of NFK");
@@ -1073,8 +1078,21 @@ k_tb_fused(const FusedArgs A) {
 
   const bool active = tid < nlev;
   const int64_t off = pin * nlev + (active ? tid : 0);
-  const double zi = A.z[off], pi = A.p[off], ti = A.t[off], rhi = A.rh[off];
+  const double zi = A.z[off], ti = A.t[off];
+  const double pi = ALPHA ? 0.0 : A.p[off], rhi = ALPHA ? 0.0 : A.rh[off];
   if (active && (isnan(zi) || isnan(pi) || isnan(ti) || isnan(rhi))) atomicOr(&s_flag, 1);
+  double awet[NFC], adry[NFC];
+  if constexpr (ALPHA) {
+    bool bad = false;
+#pragma unroll
+    for (int j = 0; j < NFC; ++j) {
+      const int64_t o = (pin * A.nf + jbase + min(j, nfc - 1)) * nlev + (active ? tid : 0);     // 512-B rows per wave
+      awet[j] = A.awet_in[o];
+      adry[j] = A.adry_in[o];
+      bad = bad || isnan(awet[j]) || isnan(adry[j]);
+    }
+    if (active && bad) atomicOr(&s_flag, 1);
+  }
   double denl = 0.0, deni = 0.0;
   if constexpr (OPT) {
     if (A.denliq) denl = A.denliq[off];
@@ -1089,8 +1107,7 @@ k_tb_fused(const FusedArgs A) {
   }
 
   // ---- phase K1: absorption at my level for the NFC frequencies ----
-  double awet[NFC], adry[NFC];
-  {
+  if constexpr (!ALPHA) {
     const double e = goff_gratch_e(ti, rhi);
     const LevelState L = level_state(pi, ti, e);
     const LineMasks lm = line_masks(M, sfq, NFC, lane);
