@@ -73,6 +73,7 @@ SIGNATURES = {
                                                   _vp, _i32, _vp, _vp, _vp, _vp]),
     "mwrt_absorption_batch": (ctypes.c_int, [_vp, _vp, _i64, _i32, _vp, _vp, _vp, _i32, _vp, _vp, _vp]),
     "mwrt_absorption_batch_device": (ctypes.c_int, [_vp, _vp, _i64, _i32, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp]),
+    "mwrt_set_absorption_mode": (ctypes.c_int, [_vp, ctypes.c_int]),
     "mwrt_selftest_math": (ctypes.c_int, [_vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp]),
     "mwrt_synchronize": (ctypes.c_int, [_vp, _vp]),
     "mwrt_set_timing": (ctypes.c_int, [_vp, ctypes.c_int]),
@@ -350,6 +351,11 @@ class Context:
             self._handle, self.model(model), int(nprof), int(nlev), _ptr(d_p), _ptr(d_t), _ptr(d_rh),
             frq.size, _ptr(frq), _ptr(d_awet), _ptr(d_adry),
             _stream(stream)), "mwrt_absorption_batch_device")
+
+    @_serialised
+    def set_absorption_mode(self, mode: int):
+        """0 automatic, 1 every line at every frequency, 2 windowed (fine grids; include/mwrt.h)."""
+        self._check(self._lib.mwrt_set_absorption_mode(self._handle, int(mode)), "mwrt_set_absorption_mode")
 
     @_serialised
     def selftest_math(self, x, y_pos):

@@ -91,8 +91,14 @@ struct mwrt_context {
   // overwritten or freed while the context lives (bar LRU eviction behind a device-wide drain), so
   // launches still queued on ANY stream and captured hipGraphs keep reading valid memory.
   ParamCache frq_cache, am_cache, elev_cache;
+  // fine-grid absorption: window descriptors + Lagrange matrices per (model, frequency list), immutable like ParamCache
+  int absorption_mode = 0;      // 0 auto, 1 direct, 2 windowed
+  struct WinEntry { const mwrt_model* model; std::vector<double> frq; WinDesc* d_win; double* d_lag; int nwin; };
+  std::vector<WinEntry> win_cache;
   // ray-tracing workspace: path factors [nprof][nang][nlev] and the per-profile ducting flag
   DevBuf d_amf, d_duct;
+  // fine-grid two-kernel path: materialised absorption of one profile batch (awet | adry)
+  DevBuf d_alpha;
   // staging for the host-buffer entry points
   DevBuf d_in, d_out, d_valid, d_ex;
   // timing: a ring of hipEvent pairs recorded around every kernel launch, on the launch stream
@@ -241,6 +247,99 @@ int pick_nfc_fused(const mwrt_context* c, int nlev, int nf, int nang) {
   return nfc;
 }
 
+// ---- fine-grid absorption: windows of WIN_CHUNKS chunks, Chebyshev nodes, Lagrange matrices ----
+constexpr double WIN_MARGIN_GHZ = 4.0;       // a line is window-far when its centre is this far beyond the window
+constexpr double WIN_MAX_SPAN_GHZ = 6.0;     // widest window the 16-node interpolation is used on
+constexpr double WIN_CUTOFF_GUARD_GHZ = 5.0; // the H2O 750-GHz cutoff must be this clearly in or out (pressure shifts < 1 GHz)
+
+bool windows_eligible(const double* frq, int nf) {
+  if (nf < WIN_CHUNKS * WIN_NFC) return false;
+  for (int j = 1; j < nf; ++j) if (!(frq[j] > frq[j - 1])) return false;
+  const int per = WIN_CHUNKS * WIN_NFC;
+  for (int b = 0; b < nf; b += per) {
+    const int e = std::min(nf, b + per) - 1;
+    if (e == b) return false;                              // a one-frequency window has no span to put nodes on
+    if (frq[e] - frq[b] > WIN_MAX_SPAN_GHZ) return false;
+  }
+  return true;
+}
+
+void build_windows(const mwrt_model_desc& t, const double* frq, int nf, std::vector<WinDesc>* wins, std::vector<double>* lag) {
+  const int per = WIN_CHUNKS * WIN_NFC;
+  const int nchunks = (nf + WIN_NFC - 1) / WIN_NFC;
+  const int nwin = (nf + per - 1) / per;
+  wins->assign(nwin, WinDesc{});
+  lag->assign((size_t)nwin * per * WIN_NODES, 0.0);
+  for (int w = 0; w < nwin; ++w) {
+    WinDesc& d = (*wins)[w];
+    const int b = w * per, e = std::min(nf, b + per) - 1;
+    const double flo = frq[b], fhi = frq[e];
+    d.first_chunk = w * WIN_CHUNKS;
+    d.nchunks = std::min(WIN_CHUNKS, nchunks - d.first_chunk);
+    long double x[WIN_NODES], bw[WIN_NODES];
+    for (int m = 0; m < WIN_NODES; ++m) {
+      x[m] = 0.5L * (flo + fhi) + 0.5L * (fhi - flo) * cosl(M_PIl * (2 * m + 1) / (2.0L * WIN_NODES));
+      d.fnode[m] = (double)x[m];
+    }
+    for (int m = 0; m < WIN_NODES; ++m) x[m] = d.fnode[m];          // weights for the nodes as the kernel sees them
+    for (int m = 0; m < WIN_NODES; ++m) {
+      long double prod = 1.0L;
+      for (int k = 0; k < WIN_NODES; ++k) if (k != m) prod *= (x[m] - x[k]);
+      bw[m] = 1.0L / prod;
+    }
+    // barycentric Lagrange weights, stored [chunk][node][target]; targets past the last frequency repeat it
+    // (their results are discarded)
+    for (int r = 0; r < per; ++r) {
+      const long double f = frq[std::min(b + r, e)];
+      const int cidx = r / WIN_NFC, j = r % WIN_NFC;
+      double* blk = lag->data() + ((size_t)w * WIN_CHUNKS + cidx) * WIN_NODES * WIN_NFC;
+      int hit = -1;
+      for (int m = 0; m < WIN_NODES; ++m) if (f == x[m]) hit = m;
+      if (hit >= 0) { blk[hit * WIN_NFC + j] = 1.0; continue; }
+      long double q[WIN_NODES], sum = 0.0L;
+      for (int m = 0; m < WIN_NODES; ++m) { q[m] = bw[m] / (f - x[m]); sum += q[m]; }
+      for (int m = 0; m < WIN_NODES; ++m) blk[m * WIN_NFC + j] = (double)(q[m] / sum);
+    }
+    // which lines are far from the whole window
+    for (int k = 0; k < t.n_o2; ++k) {
+      const double c = t.o2_f[k];
+      if (c < flo - WIN_MARGIN_GHZ || c > fhi + WIN_MARGIN_GHZ) d.o2_far |= 1ull << k;
+    }
+    for (int k = 0; k < t.n_h2o; ++k) {
+      const double c = t.h2o_fl[k];
+      if (t.h2o_w2[k] > 0.0) continue;                                 // speed-dependent lines stay direct
+      if (!(c < flo - WIN_MARGIN_GHZ || c > fhi + WIN_MARGIN_GHZ)) continue;
+      const double g = WIN_CUTOFF_GUARD_GHZ;
+      const bool d1_in = std::fabs(flo - c) < 750.0 - g && std::fabs(fhi - c) < 750.0 - g;
+      const bool d2_in = fhi + c < 750.0 - g;
+      const bool d2_out = flo + c >= 750.0 + g;
+      if (d1_in && d2_in) d.h2o_far_both |= 1u << k;
+      else if (d1_in && d2_out) d.h2o_far_res |= 1u << k;
+      // anything else (a cutoff crossing the window, or both terms out) is left to the per-chunk loops
+    }
+  }
+}
+
+int get_windows(mwrt_context* c, const mwrt_model* m, const double* frq, int nf, const WinDesc** d_win, const double** d_lag,
+                int* nwin) {
+  for (auto& e : c->win_cache)
+    if (e.model == m && (int)e.frq.size() == nf && std::memcmp(e.frq.data(), frq, sizeof(double) * nf) == 0) {
+      *d_win = e.d_win; *d_lag = e.d_lag; *nwin = e.nwin; return MWRT_OK;
+    }
+  std::vector<WinDesc> wins; std::vector<double> lag;
+  build_windows(m->h_desc, frq, nf, &wins, &lag);
+  mwrt_context::WinEntry e{m, std::vector<double>(frq, frq + nf), nullptr, nullptr, (int)wins.size()};
+  HIP_TRY(hipMalloc((void**)&e.d_win, sizeof(WinDesc) * wins.size()));
+  hipError_t err = hipMalloc((void**)&e.d_lag, sizeof(double) * lag.size());
+  if (err == hipSuccess) err = hipMemcpyAsync(e.d_win, wins.data(), sizeof(WinDesc) * wins.size(), hipMemcpyHostToDevice, c->stream);
+  if (err == hipSuccess) err = hipMemcpyAsync(e.d_lag, lag.data(), sizeof(double) * lag.size(), hipMemcpyHostToDevice, c->stream);
+  if (err == hipSuccess) err = hipStreamSynchronize(c->stream);
+  if (err != hipSuccess) { (void)hipFree(e.d_win); if (e.d_lag) (void)hipFree(e.d_lag); HIP_TRY(err); }
+  c->win_cache.push_back(std::move(e));
+  *d_win = c->win_cache.back().d_win; *d_lag = c->win_cache.back().d_lag; *nwin = c->win_cache.back().nwin;
+  return MWRT_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -280,7 +379,9 @@ int mwrt_destroy(mwrt_context* c) {
   if (!c) return MWRT_OK;
   (void)hipSetDevice(c->device);
   (void)hipStreamSynchronize(c->stream);
-  c->frq_cache.release(); c->am_cache.release(); c->elev_cache.release(); c->d_amf.release(); c->d_duct.release();
+  for (auto& e : c->win_cache) { (void)hipFree(e.d_win); (void)hipFree(e.d_lag); }
+  c->win_cache.clear();
+  c->frq_cache.release(); c->am_cache.release(); c->elev_cache.release(); c->d_amf.release(); c->d_duct.release(); c->d_alpha.release();
   c->d_in.release(); c->d_out.release();
   c->d_valid.release(); c->d_ex.release();
   for (hipEvent_t e : c->ev0) (void)hipEventDestroy(e);
@@ -326,7 +427,15 @@ int mwrt_model_create(mwrt_context* c, const mwrt_model_desc* desc, mwrt_model**
 
 int mwrt_model_destroy(mwrt_context* c, mwrt_model* m) {
   if (!m) return MWRT_OK;
-  if (c) { (void)hipSetDevice(c->device); (void)hipStreamSynchronize(c->stream); }
+  if (c) {
+    (void)hipSetDevice(c->device);
+    (void)hipDeviceSynchronize();                       // launches on any stream may still read the tables / windows
+    for (size_t i = c->win_cache.size(); i-- > 0;)      // window descriptors are keyed by the model: drop this one's
+      if (c->win_cache[i].model == m) {
+        (void)hipFree(c->win_cache[i].d_win); (void)hipFree(c->win_cache[i].d_lag);
+        c->win_cache.erase(c->win_cache.begin() + (long)i);
+      }
+  }
   if (m->d_desc) (void)hipFree(m->d_desc);
   delete m;
   return MWRT_OK;
@@ -431,6 +540,41 @@ static int tb_launch(mwrt_context* c, int nmodels, const mwrt_model* const* ms, 
       return fail(MWRT_ERR_UNSUPPORTED, "RTE from absorption: one model, no extras, no options");
     a.awet_in = d_awet; a.adry_in = d_adry;
     variant = FUSED_FROM_ALPHA;
+  }
+  // Fine spectral grids (BASELINE configs[4]): K1 -> alpha -> K2.  The windowed absorption kernel (k_absorb_win) is
+  // ~1.8x the fused kernel's K1 on such grids, which pays for sending the absorption coefficients through HBM once:
+  // profile batches of <= ALPHA_BATCH_BYTES of alpha, absorption kernel then RTE kernel, same stream.
+  if (variant == FUSED_TB_ONLY && nmodels == 1 && c->absorption_mode != 1 && nlev <= 512 && windows_eligible(frq, nf)) {
+    const WinDesc* d_win = nullptr; const double* d_lag = nullptr; int nwin = 0;
+    rc = get_windows(c, ms[0], frq, nf, &d_win, &d_lag, &nwin); if (rc) return rc;
+    constexpr size_t ALPHA_BATCH_BYTES = (size_t)4 << 30;   // 4 GiB of a 288-GB card: configs[4]'s per-GPU share is one batch
+    const size_t per_prof = (size_t)2 * nf * nlev * sizeof(double);
+    const int64_t batch = std::max<int64_t>(1, std::min<int64_t>(nprof, (int64_t)(ALPHA_BATCH_BYTES / per_prof)));
+    if ((size_t)batch * per_prof > c->d_alpha.cap) {
+      HIP_TRY(hipDeviceSynchronize());                // queued launches may still read the old workspace
+      HIP_TRY(c->d_alpha.reserve((size_t)batch * per_prof));
+    }
+    const int threads = ((nlev + WAVE - 1) / WAVE) * WAVE;
+    const int nfc2 = pick_nfc_fused(c, nlev, nf, nang);
+    for (int64_t b0 = 0; b0 < nprof; b0 += batch) {
+      const int64_t nb = std::min(batch, nprof - b0);
+      double* aw = c->d_alpha.as<double>();
+      double* ad = aw + (size_t)nb * nf * nlev;
+      AbsorbWinArgs w{};
+      w.M = ms[0]->d_desc; w.p = d_p + b0 * nlev; w.t = d_t + b0 * nlev; w.rh = d_rh + b0 * nlev; w.frq = dev_frq;
+      w.win = d_win; w.lagrange = d_lag; w.awet = aw; w.adry = ad; w.nlev = nlev; w.nf = nf;
+      timing_begin(c, st);
+      hipError_t e = launch_absorb_win(w, dim3((unsigned)nb, (unsigned)nwin), dim3(threads), st);
+      timing_end(c, st);
+      HIP_TRY(e);
+      FusedArgs a2 = a;
+      a2.nprof_in = nb;
+      a2.z = d_z + b0 * nlev; a2.p = nullptr; a2.t = d_t + b0 * nlev; a2.rh = nullptr;
+      a2.tb = d_tb + (size_t)b0 * nang * nf; a2.valid = d_valid + b0;
+      a2.awet_in = aw; a2.adry_in = ad;
+      rc = launch_fused(c, nfc2, a2, nb, st, FUSED_FROM_ALPHA); if (rc) return rc;
+    }
+    return MWRT_OK;
   }
   return launch_fused(c, pick_nfc_fused(c, nlev, nf, nang), a, rows, st, variant);
 }
@@ -588,6 +732,22 @@ int mwrt_absorption_batch_device(mwrt_context* c, const mwrt_model* m, int64_t n
   if (nprof == 0) return MWRT_OK;
   const double* dev_frq = nullptr;
   rc = upload_small(c, c->frq_cache, frq, nf, &dev_frq); if (rc) return rc;
+  const bool eligible = windows_eligible(frq, nf) && nlev <= 512;     // node sums in LDS: 2 x 16 doubles per thread
+  if (c->absorption_mode == 2 && !eligible)
+    return fail(MWRT_ERR_UNSUPPORTED, "windowed absorption needs >= 128 strictly increasing frequencies in windows <= 6 GHz wide");
+  if (eligible && c->absorption_mode != 1) {
+    const WinDesc* d_win = nullptr; const double* d_lag = nullptr; int nwin = 0;
+    rc = get_windows(c, m, frq, nf, &d_win, &d_lag, &nwin); if (rc) return rc;
+    AbsorbWinArgs w{};
+    w.M = m->d_desc; w.p = d_p; w.t = d_t; w.rh = d_rh; w.frq = dev_frq; w.win = d_win; w.lagrange = d_lag;
+    w.awet = d_awet; w.adry = d_adry; w.nlev = nlev; w.nf = nf;
+    const int threads = ((nlev + WAVE - 1) / WAVE) * WAVE;
+    timing_begin(c, st);
+    hipError_t e = launch_absorb_win(w, dim3((unsigned)nprof, (unsigned)nwin), dim3(threads), st);
+    timing_end(c, st);
+    HIP_TRY(e);
+    return MWRT_OK;
+  }
   AbsorbArgs a{};
   a.M = m->d_desc; a.p = d_p; a.t = d_t; a.rh = d_rh; a.frq = dev_frq;
   a.awet = d_awet; a.adry = d_adry; a.nlev = nlev; a.nf = nf;
@@ -616,6 +776,12 @@ int mwrt_absorption_batch(mwrt_context* c, const mwrt_model* m, int64_t nprof, i
   HIP_TRY(hipMemcpyAsync(awet, dout, nout * sizeof(double), hipMemcpyDeviceToHost, st));
   HIP_TRY(hipMemcpyAsync(adry, dout + nout, nout * sizeof(double), hipMemcpyDeviceToHost, st));
   HIP_TRY(hipStreamSynchronize(st));
+  return MWRT_OK;
+}
+
+int mwrt_set_absorption_mode(mwrt_context* c, int mode) {
+  if (!c || mode < 0 || mode > 2) return fail(MWRT_ERR_INVALID_ARGUMENT, "mode must be 0, 1 or 2");
+  c->absorption_mode = mode;
   return MWRT_OK;
 }
 

@@ -54,4 +54,21 @@ hipError_t MWRT_CAT(launch_absorb_nfc, MWRT_INST_NFC)(const AbsorbArgs& a, dim3 
   return hipGetLastError();
 }
 
+#if MWRT_INST_NFC == 16
+hipError_t launch_absorb_win(const AbsorbWinArgs& a, dim3 grid, dim3 block, hipStream_t st) {
+  // node sums in LDS: 2 x WIN_NODES doubles per thread (48 KB at 192 threads: three workgroups per CU)
+  const size_t lds = sizeof(double) * 2 * WIN_NODES * block.x;
+  if (block.x <= 256) {
+    hipError_t e = hipFuncSetAttribute((const void*)k_absorb_win<256>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL((k_absorb_win<256>), grid, block, lds, st, a);
+  } else {
+    hipError_t e = hipFuncSetAttribute((const void*)k_absorb_win<512>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL((k_absorb_win<512>), grid, block, lds, st, a);
+  }
+  return hipGetLastError();
+}
+#endif
+
 }  // namespace mwrt

@@ -23,5 +23,7 @@ MWRT_DECLARE_INST(8)
 MWRT_DECLARE_INST(14)
 MWRT_DECLARE_INST(16)
 #undef MWRT_DECLARE_INST
+// the windowed fine-grid absorption kernel exists for the 16-wide chunks only (csrc/mwrt_inst.hip, NFC = 16 unit)
+hipError_t launch_absorb_win(const AbsorbWinArgs& a, dim3 grid, dim3 block, hipStream_t st);
 
 }  // namespace mwrt

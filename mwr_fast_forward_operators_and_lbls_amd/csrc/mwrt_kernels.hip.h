@@ -430,9 +430,15 @@ __device__ __forceinline__ unsigned long long lowest_bits(unsigned long long m, 
   return out;
 }
 
-template <int NFC>
+// Window mode (k_absorb_win, fine spectral grids).  The lines far from a whole WINDOW of chunks are summed at a few
+// Chebyshev nodes of the window (NODES = true: raw line sums out, no continuum, no SD lines; a line whose per-lane
+// vote fails is reported in *failed and left out) and interpolated to each chunk's frequencies; the chunk call then
+// starts from those sums (init_sum, init_bsum) and skips the lines in `excl`.  Outside window mode: excl = 0, null.
+template <int NFC, bool NODES = false>
 __device__ __forceinline__ void h2o_absorb(cmodel M, const LevelState& L, const double* sfq /*LDS: {f, f^2} per slot*/,
-                                           const LineMasks& lm, double (&awet)[NFC]) {
+                                           const LineMasks& lm, double (&awet)[NFC], unsigned excl = 0u,
+                                           const double* init_sum = nullptr, double init_bsum = 0.0,
+                                           unsigned* failed = nullptr, double* bsum_out = nullptr) {
   const double t = L.t;
   const double pvap = fdiv(L.rho * t, M->h2o_pvap_div);
   const double pda = L.p - pvap;
@@ -445,10 +451,10 @@ __device__ __forceinline__ void h2o_absorb(cmodel M, const LevelState& L, const 
   const bool shifted = M->h2o_shift_mode != 0;
   double sum[NFC];
 #pragma unroll
-  for (int j = 0; j < NFC; ++j) sum[j] = 0.0;
+  for (int j = 0; j < NFC; ++j) sum[j] = init_sum ? init_sum[j] : 0.0;
 
   const int nl = M->n_h2o;
-  const unsigned all = (nl >= 32) ? 0xffffffffu : ((1u << nl) - 1u);
+  const unsigned all = ((nl >= 32) ? 0xffffffffu : ((1u << nl) - 1u)) & ~excl;
   // The 750-GHz cutoff of each Lorentz term depends on the lane only through the (tiny) pressure
   // shift.  Three loops, each with ONE body:
   //   A  far lines (table centre >= FAR_H2O_GHZ from every frequency), both terms inside the cutoff for
@@ -458,7 +464,7 @@ __device__ __forceinline__ void h2o_absorb(cmodel M, const LevelState& L, const 
   //   C  speed-dependent lines (22 / 183 GHz in R20SD+): Lorentz pair + the SD resonant shape.
   // Lines whose two terms are beyond the cutoff for every frequency (e.g. 916 GHz from 22 GHz) are skipped.
   const double fmin = sfq[2 * NFC], fmax = sfq[2 * NFC + 1];
-  double bsum = 0.0;                                          // sum of (count * s * base), frequency independent
+  double bsum = init_bsum;                                    // sum of (count * s * base), frequency independent
   unsigned deferred = (~lm.h2o_far | lm.h2o_res) & ~lm.h2o_sd & ~lm.h2o_none & all;
   const unsigned setA = (MWRT_ABLATE & 2) ? 0u : (lm.h2o_far & ~lm.h2o_res & ~lm.h2o_sd & ~lm.h2o_none & all);
   // loop A walks its lines FOUR at a time (far_quad_accumulate); the count mod 4 left over joins loop B
@@ -473,7 +479,10 @@ __device__ __forceinline__ void h2o_absorb(cmodel M, const LevelState& L, const 
     fl.A2 = 2.0 * __builtin_fma(-q.c1, q.c1, q.wsq);
     fl.Bc = cc * cc;
     double P = 2.0 * q.sw, bs = 2.0 * q.sbase;
-    if (!__all(d1_in && d2_in)) { deferred |= 1u << k; P = 0.0; bs = 0.0; }     // cutoff not uniform: loop B's job
+    if (!__all(d1_in && d2_in)) {                                                // cutoff not uniform: loop B's job
+      if constexpr (NODES) *failed |= 1u << k; else deferred |= 1u << k;
+      P = 0.0; bs = 0.0;
+    }
     fl.P = P;
     fl.Q = P * cc;
     bsum += bs;
@@ -521,6 +530,8 @@ __device__ __forceinline__ void h2o_absorb(cmodel M, const LevelState& L, const 
         r = __builtin_fma(r, __builtin_fma(-D1, r, 1.0), r);
         sum[j] = __builtin_fma(r, q.sw, sum[j]);
       }
+    } else if constexpr (NODES) {                               // not a smooth function of f across the window
+      *failed |= 1u << k;
     } else {                                                    // cutoff differs between lanes / frequencies: masks
 #pragma unroll
       for (int j = 0; j < NFC; ++j) {
@@ -537,6 +548,12 @@ __device__ __forceinline__ void h2o_absorb(cmodel M, const LevelState& L, const 
         sum[j] = __builtin_fma(-(m1 + m2), q.sbase, sum[j]);
       }
     }
+  }
+  if constexpr (NODES) {                                        // raw line sums at the nodes; bsum travels separately
+#pragma unroll
+    for (int j = 0; j < NFC; ++j) awet[j] = sum[j];
+    *bsum_out = bsum;
+    return;
   }
 #pragma unroll
   for (int j = 0; j < NFC; ++j) sum[j] -= bsum;
@@ -628,9 +645,10 @@ struct O2Line {            // per-(level, line) quantities, frequency independen
   double dnu;
 };
 
-template <int NFC>
+template <int NFC, bool NODES = false>
 __device__ __forceinline__ void dry_absorb(cmodel M, const LevelState& L, const double* sfq /*LDS: {f, f^2} per slot*/,
-                                           const LineMasks& lm, double (&adry)[NFC]) {
+                                           const LineMasks& lm, double (&adry)[NFC], unsigned long long excl = 0ull,
+                                           const double* init_sum = nullptr, unsigned long long* failed = nullptr) {
   const double temp = L.t;
   const double pres = L.p;
   const double th = fdiv(300.0, temp);
@@ -649,7 +667,7 @@ __device__ __forceinline__ void dry_absorb(cmodel M, const LevelState& L, const 
 
   double sum[NFC];
 #pragma unroll
-  for (int j = 0; j < NFC; ++j) sum[j] = 0.0;
+  for (int j = 0; j < NFC; ++j) sum[j] = init_sum ? init_sum[j] : 0.0;
 
   // With d1 = f - c, d2 = f + c, D = d^2 + w^2, n1 = a + d1 b, n2 = a - d2 b the two terms of a line
   // share one reciprocal and the numerator collapses to a polynomial in f^2:
@@ -683,7 +701,7 @@ __device__ __forceinline__ void dry_absorb(cmodel M, const LevelState& L, const 
   };
 
   const int nl = M->n_o2;
-  const unsigned long long all = (nl >= 64) ? ~0ull : ((1ull << nl) - 1ull);
+  const unsigned long long all = ((nl >= 64) ? ~0ull : ((1ull << nl) - 1ull)) & ~excl;
   // loop A: far lines -- polynomial denominator; a line whose shift |dnu| exceeds the allowance at any
   // level of this wave is handed to loop B
   unsigned long long near = ~lm.o2_far & all;
@@ -694,7 +712,7 @@ __device__ __forceinline__ void dry_absorb(cmodel M, const LevelState& L, const 
   auto far_setup = [&](int k, FarLine& fl) {
     const O2Line q = line_setup(k);
     double P = q.P, Q = q.Q;
-    if (second && !__all(fabs(q.dnu) < FAR_SHIFT_GHZ)) { near |= 1ull << k; P = 0.0; Q = 0.0; }
+    if (!NODES && second && !__all(fabs(q.dnu) < FAR_SHIFT_GHZ)) { near |= 1ull << k; P = 0.0; Q = 0.0; }
     fl.P = P; fl.Q = Q;
     fl.A2 = 2.0 * __builtin_fma(-q.c1, q.c1, q.df2);
     fl.Bc = q.cc * q.cc;
@@ -727,6 +745,12 @@ __device__ __forceinline__ void dry_absorb(cmodel M, const LevelState& L, const 
       r = __builtin_fma(r, __builtin_fma(-den12, r, 1.0), r);
       sum[j] = __builtin_fma(__builtin_fma(f2, q.P, q.Q), r, sum[j]);
     }
+  }
+  if constexpr (NODES) {                                        // raw half-weight line sums at the nodes
+#pragma unroll
+    for (int j = 0; j < NFC; ++j) adry[j] = sum[j];
+    (void)failed;
+    return;
   }
   const double scale2 = 2.0 * M->o2_coef * presda * th * th * th;     // the 2 of P and Q
   // N2 collision-induced continuum (ABSN2): p^2 f^2 th^m
@@ -1404,6 +1428,153 @@ k_absorb(const AbsorbArgs A) {
         A.awet[o] = awet[j];
         A.adry[o] = adry[j];
       }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// K1 on fine spectral grids: windowed evaluation (k_absorb_win)
+//
+// On a grid of hundreds of frequencies most of a chunk's 65 lines are far from the whole NEIGHBOURHOOD of the
+// chunk, and their sum is an analytic function of f there (poles at c_k +- i w_k, at least WIN_MARGIN_GHZ beyond
+// the window's ends).  A workgroup therefore owns a WINDOW of WIN_CHUNKS consecutive 16-frequency chunks of one
+// profile: it sums the window-far lines once at WIN_NODES Chebyshev nodes of the window (same line bodies as
+// everywhere else), and for each chunk interpolates those sums to the chunk's frequencies with a precomputed
+// Lagrange matrix (wave-uniform, from the host: depends on the frequencies only) and adds the remaining lines
+// -- near the window, speed dependent, or failing a per-level vote -- directly.  The per-(level, line) setup of
+// the far lines is paid once per window instead of once per chunk.
+// Interpolation error: <= 1e-10 of the line sum for spans <= 6 GHz (16 nodes, 4 GHz margin; tools/window_probe.py
+// reproduces the bound on the oracle), i.e. invisible against the 1e-6 K parity bar -- and tested against it.
+// ---------------------------------------------------------------------------------------------
+constexpr int WIN_NODES = 16;
+constexpr int WIN_CHUNKS = 8;
+constexpr int WIN_NFC = 16;
+
+struct WinDesc {                       // one per window, built by the host (csrc/mwrt.hip: build_windows)
+  double fnode[WIN_NODES];             // Chebyshev nodes of [f_lo, f_hi], GHz
+  unsigned long long o2_far;           // O2 lines >= WIN_MARGIN_GHZ beyond the window
+  unsigned h2o_far_both, h2o_far_res;  // H2O lines >= the margin beyond the window with a cutoff state uniform across it
+  int first_chunk, nchunks;            // chunks [first_chunk, first_chunk + nchunks) of the frequency list
+  int pad0, pad1;
+};
+
+struct AbsorbWinArgs {
+  const ModelFlat* M;
+  const double* p; const double* t; const double* rh;
+  const double* frq;
+  const WinDesc* win;                  // [nwin]
+  const double* lagrange;              // [nwin][WIN_CHUNKS][WIN_NODES][WIN_NFC]: weight of node m for target j of chunk c
+  double* awet; double* adry;
+  int nlev, nf;
+};
+
+template <int MAXT>
+__global__ void __launch_bounds__(MAXT, (MAXT <= 256 ? 3 : 1))
+k_absorb_win(const AbsorbWinArgs A) {
+  constexpr int NFC = WIN_NFC, NN = WIN_NODES;
+  static_assert(NN == NFC, "the node set is evaluated through the NFC-wide line bodies");
+  const int tid = threadIdx.x, lane = tid & (WAVE - 1);
+  const int64_t prof = blockIdx.x;
+  const cmodel M = (cmodel)A.M;
+  const cdoubles cfrq = (cdoubles)A.frq;
+  typedef const __attribute__((address_space(4))) WinDesc* cwin;
+  const cwin D = (cwin)(A.win + blockIdx.y);
+  const cdoubles Lw = (cdoubles)(A.lagrange + (size_t)blockIdx.y * WIN_CHUNKS * NFC * NN);
+  __shared__ double sfn[3 * NFC + 2];                        // the nodes, laid out like a chunk
+  __shared__ double sfq[3 * NFC + 2];
+  if (tid < NN) {
+    const double f = D->fnode[tid];
+    sfn[2 * tid] = f; sfn[2 * tid + 1] = f * f; sfn[2 * NFC + 2 + tid] = 1.0;
+  }
+  if (tid == WAVE - 1) {
+    double lo = D->fnode[0], hi = lo;
+    for (int j = 1; j < NN; ++j) { const double f = D->fnode[j]; lo = fmin(lo, f); hi = fmax(hi, f); }
+    sfn[2 * NFC] = lo; sfn[2 * NFC + 1] = hi;
+  }
+  __syncthreads();
+  const bool active = tid < A.nlev;
+  const int64_t off = prof * A.nlev + (active ? tid : 0);
+  const double pi = A.p[off], ti = A.t[off], rhi = A.rh[off];
+  const double e = goff_gratch_e(ti, rhi);
+  const LevelState L = level_state(pi, ti, e);
+
+  // ---- window-far lines at the nodes ----
+  // The node sums live in LDS, [node][thread] (each lane reads back only its own column: conflict-free), not in
+  // registers: 32 doubles per lane would cost the kernel two waves of occupancy.
+  extern __shared__ __attribute__((aligned(16))) double wlds[];
+  const int nthreads = blockDim.x;
+  double* Sh_l = wlds;                                        // [NN][nthreads]
+  double* So_l = wlds + (size_t)NN * nthreads;
+  const unsigned wf_both = D->h2o_far_both, wf_res = D->h2o_far_res;
+  const unsigned long long wf_o2 = D->o2_far;
+  double bsum_far = 0.0;
+  unsigned failed_h = 0u;
+  unsigned long long failed_o = 0ull;
+  {
+    LineMasks ln;
+    ln.o2_far = wf_o2; ln.h2o_far = wf_both | wf_res; ln.h2o_res = wf_res; ln.h2o_none = 0u; ln.h2o_sd = 0u;
+    double S[NN];
+    h2o_absorb<NFC, true>(M, L, sfn, ln, S, ~(wf_both | wf_res), nullptr, 0.0, &failed_h, &bsum_far);
+#pragma unroll
+    for (int m = 0; m < NN; ++m) Sh_l[m * nthreads + tid] = S[m];
+    dry_absorb<NFC, true>(M, L, sfn, ln, S, ~wf_o2, nullptr, &failed_o);
+#pragma unroll
+    for (int m = 0; m < NN; ++m) So_l[m * nthreads + tid] = S[m];
+  }
+  const unsigned excl_h = (wf_both | wf_res) & ~failed_h;     // a line that failed its vote at some level of this wave
+  const unsigned long long excl_o = wf_o2 & ~failed_o;        // was left out of the node sums: evaluated directly
+  // node sums -> a chunk's frequencies: out[j] = sum_m Lt[m][j] S[m]; the matrix is wave-uniform (scalar loads),
+  // stored node-major so one node's 16 weights are one contiguous load
+  auto interpolate = [&](const double* S_l, cdoubles Lt, double (&out)[NFC]) {
+#pragma unroll
+    for (int j = 0; j < NFC; ++j) out[j] = 0.0;
+#pragma unroll 1
+    for (int m = 0; m < NN; ++m) {                            // one node per trip: 16 scalar weights live at a time
+      const double sm = S_l[m * nthreads + tid];
+#pragma unroll
+      for (int j = 0; j < NFC; ++j) out[j] = __builtin_fma(Lt[m * NFC + j], sm, out[j]);
+    }
+  };
+
+  // ---- the window's chunks ----
+  const int nch = D->nchunks;
+  for (int c = 0; c < nch; ++c) {
+    const int jbase = (D->first_chunk + c) * NFC;
+    const int nfc = min(NFC, A.nf - jbase);
+    __syncthreads();                                          // everyone is done with the previous chunk's frequencies
+    if (tid < NFC) {
+      const double f = cfrq[jbase + min(tid, nfc - 1)];
+      sfq[2 * tid] = f; sfq[2 * tid + 1] = f * f;
+      double fdep = 1.0;
+      if (M->n2_fdep) { const double q = f * (1.0 / 450.0); fdep = 0.5 + fdiv(0.5, 1.0 + q * q); }
+      sfq[2 * NFC + 2 + tid] = fdep;
+    }
+    if (tid == WAVE - 1) {
+      double lo = cfrq[jbase], hi = lo;
+      for (int j = 1; j < nfc; ++j) { const double f = cfrq[jbase + j]; lo = fmin(lo, f); hi = fmax(hi, f); }
+      sfq[2 * NFC] = lo; sfq[2 * NFC + 1] = hi;
+    }
+    __syncthreads();
+    const cdoubles Lt = Lw + (size_t)c * NN * NFC;            // [node][target] of this chunk
+    const LineMasks lm = line_masks(M, sfq, NFC, lane);
+    // The level state is the same for every chunk, and the compiler would hoist every per-(level, line) quantity
+    // of the direct lines out of the chunk loop (hundreds of registers).  Laundering it keeps them inside.
+    LevelState Lc = L;
+    asm volatile("" : "+v"(Lc.t), "+v"(Lc.p), "+v"(Lc.rho), "+v"(Lc.pdry));
+    double init[NFC], awet[NFC], adry[NFC];
+    interpolate(Sh_l, Lt, init);
+    h2o_absorb<NFC>(M, Lc, sfq, lm, awet, excl_h, init, bsum_far);
+    if (active) {
+#pragma unroll
+      for (int j = 0; j < NFC; ++j)
+        if (j < nfc) A.awet[(prof * A.nf + jbase + j) * A.nlev + tid] = awet[j];
+    }
+    interpolate(So_l, Lt, init);
+    dry_absorb<NFC>(M, Lc, sfq, lm, adry, excl_o, init);
+    if (active) {
+#pragma unroll
+      for (int j = 0; j < NFC; ++j)
+        if (j < nfc) A.adry[(prof * A.nf + jbase + j) * A.nlev + tid] = adry[j];
     }
   }
 }

@@ -701,8 +701,10 @@ def test_extreme_inputs_track_the_oracle(gpu_ctx):
 
 def test_config5_full_per_gpu_share(gpu_ctx):
     """BASELINE config 5 at the size ONE GPU gets when 10^4 profiles are sharded over 8 (1250 profiles x
-    1000 frequencies x 7 elevations = 8.75e6 TBs, 70 MB out): finite, physically bounded, and any
-    16-frequency chunk of any profile recomputed alone is bitwise identical; a sample meets the oracle."""
+    1000 frequencies x 7 elevations = 8.75e6 TBs, 70 MB out), on the automatic fine-grid path (windowed
+    absorption kernel -> alpha in HBM -> RTE kernel, in profile batches): finite, physically bounded, any
+    16-frequency chunk of any profile recomputed alone (every line at every frequency) agrees to 1e-8 K,
+    the every-line path gives the same TBs to 1e-8 K everywhere, and a sample meets the oracle."""
     from oracle import c_oracle
     from mwr_fast_forward_operators_and_lbls_amd.distributed import shard_bounds
     lo_i, hi_i = shard_bounds(10000, 8, 3)
@@ -716,7 +718,13 @@ def test_config5_full_per_gpu_share(gpu_ctx):
     for i, c in zip(rng.integers(0, 1250, 4), rng.integers(0, 62, 4)):
         sl = slice(16 * c, 16 * c + 16)                    # one whole frequency chunk of the fused kernel
         one, _ = gpu_ctx.tb_batch("R24", P["z"][i:i + 1], P["p"][i:i + 1], P["t"][i:i + 1], P["rh"][i:i + 1], frq[sl], ang)
-        assert np.array_equal(one[0], tb[i][:, sl])
+        assert np.abs(one[0] - tb[i][:, sl]).max() <= 1e-8
+    gpu_ctx.set_absorption_mode(1)                      # the fused kernel, every line at every frequency
+    try:
+        direct, dv = gpu_ctx.tb_batch("R24", P["z"][:300], P["p"][:300], P["t"][:300], P["rh"][:300], frq, ang)
+    finally:
+        gpu_ctx.set_absorption_mode(0)
+    assert (dv == 1).all() and np.abs(direct - tb[:300]).max() <= 1e-8
     sub = np.arange(5, 1000, 83)
     r = c_oracle.tb_profile(sp.get_model("R24"), P["z"][777], P["p"][777], P["t"][777], P["rh"][777], frq[sub], ang)
     assert np.abs(tb[777][:, sub] - r["tbtotal"].reshape(7, len(sub))).max() <= TOL_K
@@ -942,3 +950,63 @@ def test_two_kernel_form_equals_the_fused_kernel(gpu_ctx):
     assert v[2] == 0 and v[7] == 2 and (np.delete(v, [2, 7]) == 1).all()
     assert np.isnan(two2[2][:, :16]).all() and np.isnan(two2[7][:, :16]).all()
     assert np.array_equal(np.delete(two2, [2, 7], axis=0), np.delete(two, [2, 7], axis=0))      # same kernel, same inputs
+
+
+@pytest.mark.parametrize("name", ["R98", "R17", "R24"])
+def test_windowed_absorption_matches_oracle_and_the_direct_kernel(gpu_ctx, name):
+    """k_absorb_win (window-far lines at 16 Chebyshev nodes + interpolation, the rest direct) against the oracle and
+    against every-line-at-every-frequency, on grids that exercise: the 60-GHz band (many near lines), a window
+    holding the 22-GHz line, a last window that is partial, a ragged last chunk, the cold sharp-line top levels."""
+    from mwr_fast_forward_operators_and_lbls_amd._native import MwrtError
+    P = pr.synthetic_profiles(5, 93)
+    m = sp.get_model(name)
+    for frq in (pr.fine_grid_frequencies(1000), np.linspace(45.0, 70.0, 777), np.linspace(18.0, 24.0, 140)):
+        res = {}
+        for mode in (1, 2):
+            gpu_ctx.set_absorption_mode(mode)
+            try:
+                res[mode] = gpu_ctx.absorption_batch(name, P["p"], P["t"], P["rh"], frq)
+            finally:
+                gpu_ctx.set_absorption_mode(0)
+        for k in (0, 1):
+            assert np.allclose(res[2][k], res[1][k], rtol=2e-10, atol=1e-300), (name, len(frq), k)
+        sub = np.arange(0, len(frq), 41)
+        aw, ad = lo.absorption_profile(m, P["p"][2], P["t"][2], P["rh"][2], frq[sub])
+        assert np.allclose(res[2][0][2][sub], aw, rtol=1e-9, atol=1e-300)
+        assert np.allclose(res[2][1][2][sub], ad, rtol=1e-9, atol=1e-300)
+    # lists the windows cannot serve fall back to the direct kernel (mode 0) or are refused (mode 2)
+    rng = np.random.default_rng(3)
+    shuffled = rng.permutation(pr.fine_grid_frequencies(1000)[:256])
+    coarse = np.linspace(20.0, 200.0, 300)                    # 77-GHz windows
+    for frq in (shuffled, coarse):
+        aw_g, ad_g = gpu_ctx.absorption_batch(name, P["p"][:2], P["t"][:2], P["rh"][:2], frq)
+        aw, ad = lo.absorption_profile(m, P["p"][1], P["t"][1], P["rh"][1], frq[::17])
+        assert np.allclose(aw_g[1][::17], aw, rtol=1e-9, atol=1e-300) and np.allclose(ad_g[1][::17], ad, rtol=1e-9, atol=1e-300)
+        gpu_ctx.set_absorption_mode(2)
+        try:
+            with pytest.raises(MwrtError) as ei:
+                gpu_ctx.absorption_batch(name, P["p"][:2], P["t"][:2], P["rh"][:2], frq)
+            assert ei.value.code == -5
+        finally:
+            gpu_ctx.set_absorption_mode(0)
+
+
+def test_windowed_path_with_fuzzed_tables(gpu_ctx):
+    """Perturbed line tables with large second-order shifts and speed dependence on random lines, through the automatic
+    fine-grid TB path (windowed K1 -> alpha -> K2), against the oracle."""
+    import dataclasses
+    rng = np.random.default_rng(17)
+    base = sp.get_model("R24")
+    o2 = {k: np.asarray(v) * (1.0 + 0.05 * rng.uniform(-1, 1, np.shape(v))) for k, v in base.o2.items()}
+    h2o = {k: np.asarray(v) * (1.0 + 0.05 * rng.uniform(-1, 1, np.shape(v))) for k, v in base.h2o.items()}
+    o2["f"], h2o["fl"] = base.o2["f"].copy(), base.h2o["fl"].copy()
+    o2["dnu0"] = rng.uniform(-0.05, 0.05, len(o2["f"])); o2["dnu1"] = rng.uniform(-0.03, 0.03, len(o2["f"]))
+    tab = dataclasses.replace(base, name="fuzzwin", alias_of=None, o2=o2, h2o=h2o)
+    P = pr.synthetic_profiles(3, 94, nlev=120)
+    frq = np.linspace(21.0, 61.0, 640)
+    ang = np.array([90.0, 8.4])
+    tb, valid = gpu_ctx.tb_batch(tab, P["z"], P["p"], P["t"], P["rh"], frq, ang)
+    assert (valid == 1).all()
+    sub = np.arange(3, 640, 53)
+    ref = lo.tb_cloud_rte(tab, P["z"][1], P["p"][1], P["t"][1], P["rh"][1], frq[sub], ang)["tbtotal"].reshape(2, -1)
+    assert np.abs(tb[1][:, sub] - ref).max() <= TOL_K

@@ -17,10 +17,15 @@ for nprof in (100, 1250):
         def run():
             ctx.tb_batch_device("R24", nprof, 180, d["z"].data_ptr(), d["p"].data_ptr(), d["t"].data_ptr(), d["rh"].data_ptr(),
                                 frq, ang, out.data_ptr(), val.data_ptr(), stream=st.cuda_stream)
-        run(); st.synchronize()
-        ctx.set_timing(True)
-        for _ in range(3): run()
-        st.synchronize()
-    ms, n = ctx.timing_collect(); ctx.set_timing(False)
-    ev = nprof * 1000 * 7
-    print(f"nprof={nprof} fused: {ms/n:8.2f} ms  {ev/(ms/n*1e-3):.3e} evals/s", flush=True)
+        for mode, name in ((1, "fused kernel, every line at every frequency"), (0, "auto: windowed K1 -> alpha -> K2")):
+            ctx.set_absorption_mode(mode)
+            run(); st.synchronize()
+            ctx.set_timing(True)
+            ncall = 3
+            for _ in range(ncall): run()
+            st.synchronize()
+            ms, n = ctx.timing_collect(); ctx.set_timing(False)
+            ev = nprof * 1000 * 7
+            print(f"nprof={nprof} {name}: {ms/ncall:8.2f} ms per call ({n // ncall} kernel launches)  {ev/(ms/ncall*1e-3):.3e} evals/s",
+                  flush=True)
+        ctx.set_absorption_mode(0)
