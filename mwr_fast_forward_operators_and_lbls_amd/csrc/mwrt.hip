@@ -99,6 +99,11 @@ struct mwrt_context {
   DevBuf d_amf, d_duct;
   // fine-grid two-kernel path: materialised absorption of one profile batch (awet | adry)
   DevBuf d_alpha;
+  // the two workspaces above are shared by consecutive calls: a call that uses one on a different stream than
+  // the previous user first waits (on the device) for that user's last kernel
+  hipEvent_t ws_event = nullptr;
+  hipStream_t ws_stream = nullptr;
+  bool ws_used = false;
   // staging for the host-buffer entry points
   DevBuf d_in, d_out, d_valid, d_ex;
   // timing: a ring of hipEvent pairs recorded around every kernel launch, on the launch stream
@@ -150,6 +155,18 @@ bool plan_fused(const mwrt_context* c, int nfc, int nlev, int nf, int nang, Laun
 
 int upload_small(mwrt_context* c, ParamCache& cache, const double* src, int n, const double** dev) {
   HIP_TRY(cache.get(src, n, c->stream, dev));
+  return MWRT_OK;
+}
+
+// Workspace hand-over between streams (ray-path factors, materialised absorption): stream-ordered, no host wait.
+int workspace_acquire(mwrt_context* c, hipStream_t st) {
+  if (!c->ws_event) HIP_TRY(hipEventCreateWithFlags(&c->ws_event, hipEventDisableTiming));
+  if (c->ws_used && c->ws_stream != st) HIP_TRY(hipStreamWaitEvent(st, c->ws_event, 0));
+  return MWRT_OK;
+}
+int workspace_release(mwrt_context* c, hipStream_t st) {
+  HIP_TRY(hipEventRecord(c->ws_event, st));
+  c->ws_stream = st; c->ws_used = true;
   return MWRT_OK;
 }
 
@@ -326,6 +343,11 @@ int get_windows(mwrt_context* c, const mwrt_model* m, const double* frq, int nf,
     if (e.model == m && (int)e.frq.size() == nf && std::memcmp(e.frq.data(), frq, sizeof(double) * nf) == 0) {
       *d_win = e.d_win; *d_lag = e.d_lag; *nwin = e.nwin; return MWRT_OK;
     }
+  if (c->win_cache.size() >= 16) {                      // bounded: drop the oldest entry behind a device-wide drain
+    HIP_TRY(hipDeviceSynchronize());
+    (void)hipFree(c->win_cache.front().d_win); (void)hipFree(c->win_cache.front().d_lag);
+    c->win_cache.erase(c->win_cache.begin());
+  }
   std::vector<WinDesc> wins; std::vector<double> lag;
   build_windows(m->h_desc, frq, nf, &wins, &lag);
   mwrt_context::WinEntry e{m, std::vector<double>(frq, frq + nf), nullptr, nullptr, (int)wins.size()};
@@ -386,6 +408,7 @@ int mwrt_destroy(mwrt_context* c) {
   c->d_valid.release(); c->d_ex.release();
   for (hipEvent_t e : c->ev0) (void)hipEventDestroy(e);
   for (hipEvent_t e : c->ev1) (void)hipEventDestroy(e);
+  if (c->ws_event) (void)hipEventDestroy(c->ws_event);
   (void)hipStreamDestroy(c->stream);
   delete c;
   return MWRT_OK;
@@ -525,6 +548,7 @@ static int tb_launch(mwrt_context* c, int nmodels, const mwrt_model* const* ms, 
       HIP_TRY(c->d_amf.reserve(need));
       HIP_TRY(c->d_duct.reserve((size_t)nprof));
     }
+    rc = workspace_acquire(c, st); if (rc) return rc;
     HIP_TRY(hipMemsetAsync(c->d_duct.p, 0, (size_t)nprof, st));
     const int rthreads = ((nlev + WAVE - 1) / WAVE) * WAVE;
     hipLaunchKernelGGL(k_ray_paths, dim3((unsigned)nprof), dim3(rthreads), 0, st, d_z, d_p, d_t, d_rh, (int)nlev, dev_elev,
@@ -554,6 +578,7 @@ static int tb_launch(mwrt_context* c, int nmodels, const mwrt_model* const* ms, 
       HIP_TRY(hipDeviceSynchronize());                // queued launches may still read the old workspace
       HIP_TRY(c->d_alpha.reserve((size_t)batch * per_prof));
     }
+    rc = workspace_acquire(c, st); if (rc) return rc;
     const int threads = ((nlev + WAVE - 1) / WAVE) * WAVE;
     const int nfc2 = pick_nfc_fused(c, nlev, nf, nang);
     for (int64_t b0 = 0; b0 < nprof; b0 += batch) {
@@ -574,9 +599,11 @@ static int tb_launch(mwrt_context* c, int nmodels, const mwrt_model* const* ms, 
       a2.awet_in = aw; a2.adry_in = ad;
       rc = launch_fused(c, nfc2, a2, nb, st, FUSED_FROM_ALPHA); if (rc) return rc;
     }
-    return MWRT_OK;
+    return workspace_release(c, st);
   }
-  return launch_fused(c, pick_nfc_fused(c, nlev, nf, nang), a, rows, st, variant);
+  rc = launch_fused(c, pick_nfc_fused(c, nlev, nf, nang), a, rows, st, variant);
+  if (rc == MWRT_OK && rays) rc = workspace_release(c, st);
+  return rc;
 }
 
 int mwrt_tb_batch_device(mwrt_context* c, const mwrt_model* m, int64_t nprof, int32_t nlev,

@@ -1010,3 +1010,35 @@ def test_windowed_path_with_fuzzed_tables(gpu_ctx):
     sub = np.arange(3, 640, 53)
     ref = lo.tb_cloud_rte(tab, P["z"][1], P["p"][1], P["t"][1], P["rh"][1], frq[sub], ang)["tbtotal"].reshape(2, -1)
     assert np.abs(tb[1][:, sub] - ref).max() <= TOL_K
+
+
+def test_workspace_paths_on_two_streams_without_host_sync(gpu_ctx):
+    """The fine-grid path (materialised absorption) and the ray-tracing path (path factors) use context workspaces
+    shared by consecutive calls.  Calls issued back to back on DIFFERENT streams, with no host synchronisation in
+    between, must not trample each other: the library orders the hand-over on the device."""
+    import torch
+    dev = torch.device("cuda:0")
+    frq = np.linspace(20.0, 60.0, 512)
+    ang = np.array([90.0, 10.0, 4.2])
+    sets = [pr.synthetic_profiles(300, 200 + k) for k in range(2)]
+    want_fine = [gpu_ctx.tb_batch("R17", P["z"], P["p"], P["t"], P["rh"], frq, ang)[0] for P in sets]
+    want_rays = [gpu_ctx.tb_batch("R17", P["z"], P["p"], P["t"], P["rh"], pr.HATPRO_FRQS, ang, ray_tracing=True)[0] for P in sets]
+    d = [{k: torch.from_numpy(P[k]).to(dev) for k in ("z", "p", "t", "rh")} for P in sets]
+    out_f = [torch.empty((300, 3, 512), dtype=torch.float64, device=dev) for _ in range(2)]
+    out_r = [torch.empty((300, 3, 14), dtype=torch.float64, device=dev) for _ in range(2)]
+    val = [torch.empty(300, dtype=torch.uint8, device=dev) for _ in range(4)]
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    torch.cuda.synchronize()
+    for rep in range(3):
+        for k in (0, 1):                                   # fine grid on stream 0 and 1, then rays on stream 1 and 0
+            gpu_ctx.tb_batch_device("R17", 300, 180, d[k]["z"].data_ptr(), d[k]["p"].data_ptr(), d[k]["t"].data_ptr(),
+                                    d[k]["rh"].data_ptr(), frq, ang, out_f[k].data_ptr(), val[k].data_ptr(),
+                                    stream=streams[k].cuda_stream)
+        for k in (0, 1):
+            gpu_ctx.tb_batch_device("R17", 300, 180, d[k]["z"].data_ptr(), d[k]["p"].data_ptr(), d[k]["t"].data_ptr(),
+                                    d[k]["rh"].data_ptr(), pr.HATPRO_FRQS, ang, out_r[k].data_ptr(), val[2 + k].data_ptr(),
+                                    stream=streams[1 - k].cuda_stream, ray_tracing=True)
+    torch.cuda.synchronize()
+    for k in (0, 1):
+        assert np.array_equal(out_f[k].cpu().numpy(), want_fine[k]), k
+        assert np.array_equal(out_r[k].cpu().numpy(), want_rays[k]), k

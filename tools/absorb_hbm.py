@@ -2,7 +2,8 @@
 """The absorption kernel (K1 alone, mwrt_absorption_batch_device) on BASELINE configs[4]'s per-GPU
 share: 1250 profiles x 180 levels x 1000 frequencies -> awet, adry = 3.6 GB written.
 
-    python tools/absorb_hbm.py [nprof] [reps] [model]       # prints one JSON line
+    python tools/absorb_hbm.py [nprof] [reps] [model] [mode]      # prints one JSON line
+mode 0 (default) = automatic: the windowed kernel k_absorb_win on this grid; 1 = k_absorb, every line at every frequency.
 
 Run plain for the HIP-event timing, or under rocprofv3 (program directly after `--`):
     rocprofv3 --kernel-trace --stats -d gpurun_out/abs_trace -- python3 tools/absorb_hbm.py
@@ -21,8 +22,10 @@ from mwr_fast_forward_operators_and_lbls_amd import _native as nat, profiles as 
 nprof = int(sys.argv[1]) if len(sys.argv) > 1 else 1250
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 5
 model = sys.argv[3] if len(sys.argv) > 3 else "R24"
+mode = int(sys.argv[4]) if len(sys.argv) > 4 else 0
 nlev, nf = 180, 1000
 ctx = nat.Context(0)
+ctx.set_absorption_mode(mode)
 dev = torch.device("cuda:0")
 frq = pr.fine_grid_frequencies(nf)
 P = pr.synthetic_profiles(nprof, 5)
@@ -45,7 +48,7 @@ ctx.set_timing(False)
 kernel_ms = ms / n
 abytes = nprof * nlev * (3 * 8 + nf * 16) + nf * 8
 gbs = abytes / (kernel_ms * 1e-3) / 1e9
-print(json.dumps({"kernel": "k_absorb", "workload": f"{nprof} profiles x {nlev} levels x {nf} frequencies, model {model}",
+print(json.dumps({"kernel": "k_absorb (every line at every frequency)" if mode == 1 else "k_absorb_win (windowed)", "workload": f"{nprof} profiles x {nlev} levels x {nf} frequencies, model {model}",
                   "kernel_ms": kernel_ms, "launches": n, "algorithmic_bytes_per_launch": abytes,
                   "hbm_gbs": gbs, "hbm_frac_of_8TBs": gbs / roofline.HBM_PEAK_GBS,
                   "points_per_s": nprof * nlev * nf / (kernel_ms * 1e-3),

@@ -17,11 +17,19 @@ bash tools/pmc_passes.sh $OUT/pmc_cfg3 3 > /dev/null
 python3 tools/pmc_summary.py $OUT/pmc_cfg3 > $OUT/pmc_cfg3.txt
 bash tools/pmc_passes.sh $OUT/pmc_cfg2 2 > /dev/null
 python3 tools/pmc_summary.py $OUT/pmc_cfg2 > $OUT/pmc_cfg2.txt
-# 3. the absorption kernel on configs[4]'s per-GPU share
-python3 tools/absorb_hbm.py 1250 5 > $OUT/absorb.json 2> $OUT/absorb.err
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/abs_trace -- python3 tools/absorb_hbm.py 1250 3 > $OUT/abs_trace.json 2> $OUT/abs_trace.err
+# 3. the absorption kernels on configs[4]'s per-GPU share: windowed (automatic) and every-line-at-every-frequency
+python3 tools/absorb_hbm.py 1250 5 R24 0 > $OUT/absorb_win.json 2> $OUT/absorb.err
+python3 tools/absorb_hbm.py 1250 5 R24 1 > $OUT/absorb_direct.json 2>> $OUT/absorb.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/abs_trace -- python3 tools/absorb_hbm.py 1250 3 R24 0 > $OUT/abs_trace.json 2> $OUT/abs_trace.err
 cp $(ls $OUT/abs_trace/*/*kernel_stats.csv | head -1) $OUT/absorb_kernel_stats.csv
-rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/abs_pmc/w -- python3 tools/absorb_hbm.py 1250 2 > /dev/null 2> $OUT/abs_w.err
-rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/abs_pmc/f -- python3 tools/absorb_hbm.py 1250 2 > /dev/null 2> $OUT/abs_f.err
-python3 tools/pmc_summary.py $OUT/abs_pmc k_absorb > $OUT/absorb_pmc.txt
-cat $OUT/bench_cfg3_kernel_stats.csv $OUT/pmc_cfg3.txt $OUT/absorb.json $OUT/absorb_kernel_stats.csv $OUT/absorb_pmc.txt
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/abs_pmc/w -- python3 tools/absorb_hbm.py 1250 2 R24 0 > /dev/null 2> $OUT/abs_w.err
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/abs_pmc/f -- python3 tools/absorb_hbm.py 1250 2 R24 0 > /dev/null 2> $OUT/abs_f.err
+python3 tools/pmc_summary.py $OUT/abs_pmc k_absorb_win > $OUT/absorb_pmc.txt
+# 4. the two-kernel fine-grid form next to the fused kernel, and its kernel trace
+python3 tools/two_kernel_finegrid.py 1250 > $OUT/two_kernel.json 2> $OUT/two_kernel.err
+python3 tools/finegrid_time.py 2>/dev/null | grep nprof > $OUT/finegrid.txt
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/two_trace -- python3 tools/two_kernel_finegrid.py 1250 > /dev/null 2> $OUT/two_trace.err
+cp $(ls $OUT/two_trace/*/*kernel_stats.csv | head -1) $OUT/two_kernel_stats.csv
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/two_pmc/f -- python3 tools/two_kernel_finegrid.py 1250 > /dev/null 2> $OUT/two_f.err
+python3 tools/pmc_summary.py $OUT/two_pmc "k_tb_fused<16, 8, 256, false, false, true>" > $OUT/two_kernel_pmc.txt
+cat $OUT/bench_cfg3_kernel_stats.csv $OUT/pmc_cfg3.txt $OUT/absorb_win.json $OUT/absorb_direct.json $OUT/absorb_kernel_stats.csv $OUT/absorb_pmc.txt $OUT/two_kernel.json $OUT/finegrid.txt $OUT/two_kernel_pmc.txt

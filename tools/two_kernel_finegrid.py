@@ -1,5 +1,5 @@
 """BASELINE configs[4]'s per-GPU share (1250 profiles x 1000 frequencies x 7 elevations) as TWO kernels --
-K1 (k_absorb) writes awet / adry (3.6 GB), K2 (k_tb_fused<ALPHA>) reads them back and integrates -- next to the
+K1 (k_absorb_win, the windowed absorption kernel; k_absorb for comparison) writes awet / adry (3.6 GB), K2 (k_tb_fused<ALPHA>) reads them back and integrates -- next to the
 fused kernel that keeps everything on chip.  Prints kernel times and algorithmic HBM GB/s of each.
 
     python tools/two_kernel_finegrid.py [nprof]
@@ -39,7 +39,8 @@ def fused():
 
 res = {}
 with torch.cuda.stream(st):
-    for name, fn in (("k1_absorb", k1), ("k2_from_alpha", k2), ("fused", fused)):
+    for name, fn, mode in (("k1_direct", k1, 1), ("k1_absorb", k1, 0), ("k2_from_alpha", k2, 0), ("fused", fused, 1)):
+        ctx.set_absorption_mode(mode)      # 1: every line at every frequency (k_absorb / plain fused kernel); 0: windowed K1
         fn(); st.synchronize()
         ctx.set_timing(True)
         for _ in range(3):
@@ -47,10 +48,12 @@ with torch.cuda.stream(st):
         st.synchronize()
         ms, n = ctx.timing_collect(); ctx.set_timing(False)
         res[name] = ms / n
+    ctx.set_absorption_mode(0)
 alpha_bytes = nprof * nlev * nf * 16
 io_small = nprof * nlev * 3 * 8
 res_json = {
     "workload": f"{nprof} profiles x {nlev} levels x {nf} frequencies x {nang} elevations, model R24",
+    "k1_direct_ms": res["k1_direct"], "k1_direct_hbm_gbs": (alpha_bytes + io_small) / (res["k1_direct"] * 1e-3) / 1e9,
     "k1_absorb_ms": res["k1_absorb"], "k1_hbm_gbs": (alpha_bytes + io_small) / (res["k1_absorb"] * 1e-3) / 1e9,
     "k2_from_alpha_ms": res["k2_from_alpha"],
     "k2_hbm_gbs": (alpha_bytes + nprof * nang * nf * 8 + nprof * nlev * 16) / (res["k2_from_alpha"] * 1e-3) / 1e9,
