@@ -7,6 +7,7 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -99,6 +100,7 @@ struct mwrt_context {
   DevBuf d_amf, d_duct;
   // fine-grid two-kernel path: materialised absorption of one profile batch (awet | adry)
   DevBuf d_alpha;
+  size_t alpha_batch_bytes = (size_t)4 << 30;   // 4 GiB of a 288-GB card: configs[4]'s per-GPU share is one batch
   // the two workspaces above are shared by consecutive calls: a call that uses one on a different stream than
   // the previous user first waits (on the device) for that user's last kernel
   hipEvent_t ws_event = nullptr;
@@ -393,6 +395,10 @@ int mwrt_create(int device_id, mwrt_context** out) {
   int lds = 0;
   if (hipDeviceGetAttribute(&lds, hipDeviceAttributeMaxSharedMemoryPerBlock, device_id) == hipSuccess && lds > 0)
     c->lds_max = lds;
+  if (const char* mb = std::getenv("MWRT_ALPHA_BATCH_MB")) {       // diagnostic: size of a fine-grid profile batch
+    const long v = std::atol(mb);
+    if (v > 0) c->alpha_batch_bytes = (size_t)v << 20;
+  }
   *out = c;
   return MWRT_OK;
 }
@@ -571,7 +577,7 @@ static int tb_launch(mwrt_context* c, int nmodels, const mwrt_model* const* ms, 
   if (variant == FUSED_TB_ONLY && nmodels == 1 && c->absorption_mode != 1 && nlev <= 512 && windows_eligible(frq, nf)) {
     const WinDesc* d_win = nullptr; const double* d_lag = nullptr; int nwin = 0;
     rc = get_windows(c, ms[0], frq, nf, &d_win, &d_lag, &nwin); if (rc) return rc;
-    constexpr size_t ALPHA_BATCH_BYTES = (size_t)4 << 30;   // 4 GiB of a 288-GB card: configs[4]'s per-GPU share is one batch
+    const size_t ALPHA_BATCH_BYTES = c->alpha_batch_bytes;
     const size_t per_prof = (size_t)2 * nf * nlev * sizeof(double);
     const int64_t batch = std::max<int64_t>(1, std::min<int64_t>(nprof, (int64_t)(ALPHA_BATCH_BYTES / per_prof)));
     if ((size_t)batch * per_prof > c->d_alpha.cap) {

@@ -1042,3 +1042,25 @@ def test_workspace_paths_on_two_streams_without_host_sync(gpu_ctx):
     for k in (0, 1):
         assert np.array_equal(out_f[k].cpu().numpy(), want_fine[k]), k
         assert np.array_equal(out_r[k].cpu().numpy(), want_rays[k]), k
+
+
+def test_fine_grid_path_in_several_profile_batches(gpu_ctx, monkeypatch):
+    """The automatic fine-grid path materialises absorption for one PROFILE BATCH at a time (4 GiB by default: one batch
+    for the configs[4] share).  With the batch shrunk to 8 MB (MWRT_ALPHA_BATCH_MB, read at context creation) 40
+    profiles take 14 batches; results must equal the single-batch ones bit for bit, NaN profile included."""
+    from mwr_fast_forward_operators_and_lbls_amd import _native
+    P = pr.synthetic_profiles(40, 95)
+    P["t"][17, 60] = np.nan
+    frq = np.linspace(22.0, 60.0, 700)
+    ang = np.array([90.0, 19.2, 5.4])
+    one, v1 = gpu_ctx.tb_batch("R17", P["z"], P["p"], P["t"], P["rh"], frq, ang)
+    monkeypatch.setenv("MWRT_ALPHA_BATCH_MB", "8")
+    ctx = _native.Context(0)
+    try:
+        many, v2 = ctx.tb_batch("R17", P["z"], P["p"], P["t"], P["rh"], frq, ang)
+    finally:
+        ctx.close()
+    assert np.array_equal(v1, v2) and v1[17] == 0 and v1.sum() == 39
+    assert np.array_equal(np.isnan(one), np.isnan(many)) and np.array_equal(np.nan_to_num(one), np.nan_to_num(many))
+    ref = lo.tb_cloud_rte(sp.get_model("R17"), P["z"][33], P["p"][33], P["t"][33], P["rh"][33], frq[::50], ang)["tbtotal"]
+    assert np.abs(many[33][:, ::50].ravel() - ref).max() <= TOL_K
