@@ -580,10 +580,14 @@ static int tb_launch(mwrt_context* c, int nmodels, const mwrt_model* const* ms, 
     const size_t ALPHA_BATCH_BYTES = c->alpha_batch_bytes;
     const size_t per_prof = (size_t)2 * nf * nlev * sizeof(double);
     const int64_t batch = std::max<int64_t>(1, std::min<int64_t>(nprof, (int64_t)(ALPHA_BATCH_BYTES / per_prof)));
+    bool have_ws = true;
     if ((size_t)batch * per_prof > c->d_alpha.cap) {
       HIP_TRY(hipDeviceSynchronize());                // queued launches may still read the old workspace
-      HIP_TRY(c->d_alpha.reserve((size_t)batch * per_prof));
+      const hipError_t e = c->d_alpha.reserve((size_t)batch * per_prof);
+      if (e == hipErrorOutOfMemory) { (void)hipGetLastError(); have_ws = false; }   // no room for alpha: the fused kernel
+      else HIP_TRY(e);                                                              // needs no workspace at all
     }
+    if (have_ws) {
     rc = workspace_acquire(c, st); if (rc) return rc;
     const int threads = ((nlev + WAVE - 1) / WAVE) * WAVE;
     const int nfc2 = pick_nfc_fused(c, nlev, nf, nang);
@@ -606,6 +610,7 @@ static int tb_launch(mwrt_context* c, int nmodels, const mwrt_model* const* ms, 
       rc = launch_fused(c, nfc2, a2, nb, st, FUSED_FROM_ALPHA); if (rc) return rc;
     }
     return workspace_release(c, st);
+    }
   }
   rc = launch_fused(c, pick_nfc_fused(c, nlev, nf, nang), a, rows, st, variant);
   if (rc == MWRT_OK && rays) rc = workspace_release(c, st);
