@@ -24,6 +24,7 @@ import numpy as np
 from . import _native
 from .dataset import Dataset
 from . import spectroscopy
+from . import netcdf4_io
 
 ##############################################################################
 # Parameters (reference :35-37)
@@ -44,7 +45,7 @@ def parse_arguments(argv=None):
     outfile = "3_campaigns_PyRTlib_R24_processed_TBs_from_rs.nc"
     parser.add_argument("--input", "-i", type=str,
                         default=os.path.expanduser(outpath + "MWR_rs_FESSTVaLSoclesVital1_all_elevations.nc"),
-                        help="NetCDF (needs xarray) or .npz file with rs and MWR data")
+                        help="NetCDF (xarray if installed, else libhdf5 / scipy directly) or .npz file with rs and MWR data")
     parser.add_argument("--output", "-o", type=str, default=os.path.expanduser(outpath + outfile),
                         help="Where to save summarized inputs and output TBs")
     # not in the reference (it runs pyrtlib's defaults): opt-in physics, off unless asked for
@@ -52,6 +53,8 @@ def parse_arguments(argv=None):
                         help="add cloud liquid / ice absorption from Level_Liquid / Level_Ice [kg/kg]")
     parser.add_argument("--ray-tracing", action="store_true",
                         help="spherical refracted slant paths instead of dz / sin(elevation)")
+    parser.add_argument("--netcdf4", action="store_true",
+                        help="without xarray: write NETCDF4_CLASSIC through libhdf5 (as the reference does) instead of NetCDF-3")
     return parser.parse_args(argv)
 
 
@@ -181,27 +184,35 @@ def derive_TBs4PyRTlib(ds, args=None, cloudy=None, ray_tracing=None):
 
 
 def open_dataset(path: str):
-    """``xr.open_dataset`` when xarray is importable (:205), else the .npz exchange format."""
+    """``xr.open_dataset`` when xarray is importable (:205); without it NetCDF-4 files are read through
+    libhdf5 (netcdf4_io), NetCDF-3 through scipy, and ``.npz`` is the exchange format."""
     if path.endswith(".npz"):
         return Dataset.from_npz(path)
     try:
         import xarray as xr
     except ImportError:
         with open(path, "rb") as fh:
-            magic = fh.read(4)
+            magic = fh.read(8)
         if magic[:3] == b"CDF":                     # NetCDF-3 classic / 64-bit offset: scipy can read it
             return Dataset.from_netcdf3(path)
-        raise ImportError("this file is NetCDF-4/HDF5 and reading it needs xarray + netCDF4, which this image "
-                          "lacks; convert to NetCDF-3 or .npz (dataset.Dataset)") from None
+        if magic == netcdf4_io.HDF5_MAGIC:
+            try:
+                return netcdf4_io.read_netcdf4(path)
+            except ImportError as err:
+                raise ImportError(f"{path} is NetCDF-4/HDF5: reading it needs xarray + netCDF4 or an HDF5 shared "
+                                  f"library ({err}); or convert to NetCDF-3 / .npz (dataset.Dataset)") from None
+        raise ValueError(f"{path}: neither NetCDF-3, NetCDF-4/HDF5 nor .npz")
     return xr.open_dataset(path)
 
 
-def write_dataset(ds, path: str):
+def write_dataset(ds, path: str, netcdf4: bool = False):
     if isinstance(ds, Dataset):
         if path.endswith(".npz"):
             ds.to_npz(path)
+        elif netcdf4:
+            netcdf4_io.write_netcdf4(ds, path, classic=True)      # the reference's format (:211), via libhdf5
         else:
-            ds.to_netcdf3(path)                       # NetCDF-3 classic: what scipy can write here
+            ds.to_netcdf3(path)                       # NetCDF-3 classic (scipy): opens in xarray / libnetcdf as is
     else:
         ds.to_netcdf(path, format="NETCDF4_CLASSIC")      # reference :211
 
@@ -210,4 +221,4 @@ if __name__ == "__main__":
     args = parse_arguments()
     ds = open_dataset(args.input)
     ds = derive_TBs4PyRTlib(ds, args)
-    write_dataset(ds, args.output)
+    write_dataset(ds, args.output, netcdf4=args.netcdf4)
