@@ -39,7 +39,10 @@
  * frequencies in chunks (14 or 16 per workgroup) and choose per chunk between algebraically
  * equal forms of a line's denominator (polynomial in f^2 away from line centres, direct
  * detunings next to them), so the TB of one frequency may differ by <= 1e-8 K depending on
- * which other frequencies share its call.  Against the 1e-6 K parity bar this is invisible.
+ * which other frequencies share its call.  Likewise the layer integration picks, per wave of
+ * (frequency, elevation) pairs, between two algebraically equal forms of a layer's emission
+ * (thin layers: series, no division), so a TB may differ by <= 1e-10 K depending on which
+ * other elevations share its call.  Against the 1e-6 K parity bar both are invisible.
  *
  * Streams: the *_device entry points are asynchronous on `stream`:
  *   NULL               the context's own stream (hipStreamNonBlocking: NOT ordered with the

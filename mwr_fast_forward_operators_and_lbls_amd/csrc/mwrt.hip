@@ -123,8 +123,8 @@ struct mwrt_model {
 namespace {
 
 // K2 work split: items = pairs x nseg over `threads` lanes; cost ~ rounds x seglen (+ combine)
-LaunchGeom plan_k2(int nlev, int npairs, int threads) {
-  LaunchGeom g;
+// segments per (frequency, angle) pair for one K2 pass of `npairs` pairs: fill the workgroup in one round
+int plan_k2_pass(int nlev, int npairs, int threads) {
   const int layers = nlev - 1;
   int best = 1; long best_cost = -1;
   for (int ns = 1; ns <= 64 && ns <= (layers > 0 ? layers : 1); ++ns) {
@@ -133,9 +133,26 @@ LaunchGeom plan_k2(int nlev, int npairs, int threads) {
     const long cost = rounds * (sl * 8L + 4) + ns;      // 8 ~ relative cost of a layer step vs a combine step
     if (best_cost < 0 || cost < best_cost) { best_cost = cost; best = ns; }
   }
-  g.nseg = best;
-  g.seglen = (layers + best - 1) / best;
-  if (g.seglen < 1) g.seglen = 1;
+  return best;
+}
+
+// rows kept in LDS per K2 pass; a 14-wide chunk runs as passes of 8 and 6 rows, each with its own split
+int nfk_of(int /*nfc*/) { return 8; }
+
+void set_pass(LaunchGeom* g, int h, int nlev, int ns) {
+  g->nseg[h] = ns < 1 ? 1 : ns;
+  g->seglen[h] = (nlev - 1 + g->nseg[h] - 1) / g->nseg[h];
+  if (g->seglen[h] < 1) g->seglen[h] = 1;
+}
+
+LaunchGeom plan_k2(int nlev, int nfc, int nf, int nang, int threads) {
+  LaunchGeom g;
+  const int nfk = nfk_of(nfc);
+  const int rows0 = std::min(nfk, std::min(nfc, nf));
+  const int rows1 = std::max(0, std::min(nfc, nf) - nfk);
+  set_pass(&g, 0, nlev, plan_k2_pass(nlev, rows0 * nang, threads));
+  set_pass(&g, 1, nlev, rows1 > 0 ? plan_k2_pass(nlev, rows1 * nang, threads) : 1);
+  g.npart = 2 * nang * std::max(rows0 * g.nseg[0], rows1 * g.nseg[1]);
   // row stride in doubles: odd multiple of 2 dwords keeps ds_read_b64 rows on distinct banks
   int ld = nlev + 1;
   if ((ld & 1) == 0) ld += 1;
@@ -143,13 +160,12 @@ LaunchGeom plan_k2(int nlev, int npairs, int threads) {
   return g;
 }
 
-// rows kept in LDS per K2 pass for a chunk width
-int nfk_of(int nfc) { return nfc == 14 ? 7 : 8; }
-
-size_t fused_lds_bytes(int nfc, const LaunchGeom& g, int nang, int threads) {
+size_t fused_lds_bytes(int nfc, const LaunchGeom& g, int /*nang*/, int threads) {
   const int nfk = nfk_of(nfc);
-  return sizeof(double) * ((size_t)2 * nfk * g.ldrow + (size_t)3 * nfk * nang * g.nseg + 16 +
-                           (size_t)(threads / WAVE) * 2 * nfc);
+  // float gmax[nfk][threads/16], int wcnt[nwaves], int perm[threads]
+  const size_t sort_doubles = ((size_t)nfk * (threads / 16) + (threads / WAVE) + threads + 1) / 2;
+  return sizeof(double) * ((size_t)2 * nfk * g.ldrow + (size_t)g.npart + 16 +
+                           (size_t)(threads / WAVE) * 2 * nfc + sort_doubles);
 }
 
 // K2 split for a chunk width, shrunk until the workgroup's LDS fits; false if it cannot
@@ -242,11 +258,14 @@ int launch_absorb(mwrt_context* c, int nfc, const AbsorbArgs& a, int64_t nprof, 
 
 bool plan_fused(const mwrt_context* c, int nfc, int nlev, int nf, int nang, LaunchGeom* g, size_t* lds) {
   const int threads = ((nlev + WAVE - 1) / WAVE) * WAVE;
-  *g = plan_k2(nlev, std::min(nfk_of(nfc), nf) * nang, threads);
+  *g = plan_k2(nlev, nfc, nf, nang, threads);
   *lds = fused_lds_bytes(nfc, *g, nang, threads);
-  while (*lds > (size_t)c->lds_max && g->nseg > 1) {     // shrink the partials if LDS is short
-    g->nseg = (g->nseg + 1) / 2;
-    g->seglen = (nlev - 1 + g->nseg - 1) / g->nseg;
+  while (*lds > (size_t)c->lds_max && (g->nseg[0] > 1 || g->nseg[1] > 1)) {     // shrink the partials if LDS is short
+    const int nfk = nfk_of(nfc);
+    const int rows0 = std::min(nfk, std::min(nfc, nf)), rows1 = std::max(0, std::min(nfc, nf) - nfk);
+    set_pass(g, 0, nlev, (g->nseg[0] + 1) / 2);
+    set_pass(g, 1, nlev, (g->nseg[1] + 1) / 2);
+    g->npart = 2 * nang * std::max(rows0 * g->nseg[0], rows1 * g->nseg[1]);
     *lds = fused_lds_bytes(nfc, *g, nang, threads);
   }
   return *lds <= (size_t)c->lds_max;

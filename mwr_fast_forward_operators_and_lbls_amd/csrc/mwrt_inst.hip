@@ -11,7 +11,7 @@ namespace mwrt {
 namespace {
 
 constexpr int NFC = MWRT_INST_NFC;
-constexpr int NFK = (NFC == 14) ? 7 : 8;
+constexpr int NFK = 8;
 
 template <int MAXT, bool OPT, bool EXTRAS, bool ALPHA>
 hipError_t launch_one(const FusedArgs& a, dim3 grid, dim3 block, size_t lds, hipStream_t st) {

@@ -21,6 +21,7 @@ namespace mwrt {
 
 constexpr int WAVE = 64;
 constexpr double TAUMAX = 125.0;
+constexpr double TRANS_MIN = 5.1664206328378610e-55;   // exp(-TAUMAX)
 
 // Device image of the tables: the ABI record plus host-precomputed reciprocals.  It is read
 // through a CONSTANT-address-space pointer: the tables never change while a kernel runs, and
@@ -39,9 +40,10 @@ struct ModelFlat : mwrt_model_desc {
 typedef const __attribute__((address_space(4))) ModelFlat* cmodel;
 typedef const __attribute__((address_space(4))) double* cdoubles;
 
-struct LaunchGeom {          // host-computed K2 work split (see plan_k2 in mwrt.hip)
-  int nseg;                  // level segments per (freq, angle) pair
-  int seglen;                // layers per segment
+struct LaunchGeom {          // host-computed K2 work split (see plan_k2 in mwrt.hip), per K2 pass
+  int nseg[2];               // level segments per (freq, angle) pair
+  int seglen[2];             // layers per segment
+  int npart;                 // doubles of segment partials (B, T) the largest pass needs
   int ldrow;                 // padded LDS row length (doubles) of tau/boft: conflict-free for b64
 };
 
@@ -137,11 +139,12 @@ __device__ __forceinline__ double flog(double x) {
 #endif
 }
 
-// exp(x) for |x| <= 1/16 with no range reduction: degree-9 Taylor (truncation 2.5e-19).  10 VALU.
-// Thin layers (tau * airmass <= 1/16) are the rule for the K-band channels at every level and angle.
-constexpr double EXP_SMALL_X = 0.0625;
+// exp(x) for |x| <= 1/8 with no range reduction: degree-10 Taylor (truncation 3e-18).  11 VALU.
+// Thin layers (tau * airmass <= 1/8) are the rule for the K-band channels at every level and angle.
+constexpr double EXP_SMALL_X = 0.125;
 __device__ __forceinline__ double fexp_small(double x) {
-  double p = 2.7557319223985888e-06;                 // 1/9!
+  double p = 2.7557319223985891e-07;                 // 1/10!
+  MWRT_FMA_SC(p, x, 2.7557319223985888e-06);         // 1/9!
   MWRT_FMA_SC(p, x, 2.4801587301587302e-05);         // 1/8!
   MWRT_FMA_SC(p, x, 1.9841269841269841e-04);         // 1/7!
   MWRT_FMA_SC(p, x, 1.3888888888888889e-03);         // 1/6!
@@ -152,6 +155,31 @@ __device__ __forceinline__ double fexp_small(double x) {
   p = __builtin_fma(p, x, 1.0);
   return __builtin_fma(p, x, 1.0);
 }
+
+// tanh(x/2) = (1 - e^-x) / (1 + e^-x) for 0 <= x <= 1/8: odd series through x^11 (next term 1e-17 relative).
+// 7 VALU; in the thin-layer RTE step it replaces 1 - E, 1 + E and their quotient (9 issue slots), and has none
+// of the cancellation of 1 - E.
+__device__ __forceinline__ double ftanh_half_small(double x) {
+  const double u = x * x;
+  double p = -4.3277517235850570e-06;                // -691/159667200
+  MWRT_FMA_SC(p, u, 4.2713844797178131e-05);         // 31/725760
+  MWRT_FMA_SC(p, u, -4.2162698412698413e-04);        // -17/40320
+  MWRT_FMA_SC(p, u, 4.1666666666666666e-03);         // 1/240
+  MWRT_FMA_SC(p, u, -4.1666666666666664e-02);        // -1/24
+  p = __builtin_fma(p, u, 0.5);
+  return p * x;
+}
+
+// max over the 16 lanes of a DPP row (lanes 16k .. 16k+15), delivered to all of them: row_ror 8, 4, 2, 1.
+// Four VALU instructions, no LDS crossbar.
+__device__ __forceinline__ float row16_max(float m) {
+  m = fmaxf(m, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(m), 0x128, 0xf, 0xf, false)));
+  m = fmaxf(m, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(m), 0x124, 0xf, 0xf, false)));
+  m = fmaxf(m, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(m), 0x122, 0xf, 0xf, false)));
+  m = fmaxf(m, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(m), 0x121, 0xf, 0xf, false)));
+  return m;
+}
+constexpr int K2_SORT_MIN_SEGLEN = 16;     // shorter segments: dealing the items out costs more than the thin step saves
 
 // Planck function in pyrtlib's units, B = 1 / (exp(x) - 1), x = h f / (k T).  In the microwave x is a few
 // 1e-3: when the whole wave has x <= 1/32 the series (e^x - 1)/x = sum x^n/(n+1)! (8 terms, truncation
@@ -791,16 +819,17 @@ __device__ __forceinline__ void dry_absorb(cmodel M, const LevelState& L, const 
 // quotient form, which loses up to 1e-7 relative when x1 - x0 is just above the 1e-9 switch.
 constexpr double LOGMEAN_SMALL_S = 0.1715;      // |s| <= this: series truncation < 1.1e-19
 template <bool ZEROFLG = true>
-__device__ __forceinline__ double layer_value(double x1, double x0, bool& neg) {
+__device__ __forceinline__ double layer_value(double x1, double x0, bool& neg, bool live = true) {
+  // live = this lane holds a layer (its result is used): the wave votes ignore the others
   const double d = x1 - x0;
   const double sm = x1 + x0;
   const bool negative = (x0 < 0.0) | (x1 < 0.0);
   const bool same = fabs(d) < 1e-09;
   const bool zero = x0 == 0.0 || x1 == 0.0;
-  const bool special = negative || same || zero;
+  const bool special = live && (negative || same || zero);
   double r;
   const double s = fdiv1(d, sm);
-  if (__all(special || fabs(s) <= LOGMEAN_SMALL_S)) {
+  if (__all(!live || special || fabs(s) <= LOGMEAN_SMALL_S)) {
     // s / atanh(s) = 1 - z/3 - 4 z^2/45 - 44 z^3/945 - ... (z = s^2; coefficients by series inversion,
     // truncation after z^10 < 1.1e-19 at |s| = 0.1715): the log-mean is (x1 + x0)/2 times this
     const double z = s * s;
@@ -819,10 +848,12 @@ __device__ __forceinline__ double layer_value(double x1, double x0, bool& neg) {
   } else {
     r = fdiv1(d, flog(fdiv(x1, x0)));
   }
-  if (negative) neg = true;
-  r = zero ? (ZEROFLG ? sm * 0.5 : 0.0) : r;                   // zeroflg = True for wet & dry, False for liquid & ice
-  r = same ? x1 : r;
-  r = negative ? 0.0 : r;
+  if (__any(special)) {                                        // rare below the stratosphere: wave-uniform skip (and 12 VGPRs fewer live)
+    if (negative && live) neg = true;
+    r = zero ? (ZEROFLG ? sm * 0.5 : 0.0) : r;                 // zeroflg = True for wet & dry, False for liquid & ice
+    r = same ? x1 : r;
+    r = negative ? 0.0 : r;
+  }
   return r;
 }
 
@@ -1070,8 +1101,8 @@ __device__ __forceinline__ void blank_outputs(const FusedArgs& A, int64_t prof, 
 template <int NFC, int NFK, int MAXT, bool OPT = false, bool EXTRAS = false, bool ALPHA = false>
 __global__ void __launch_bounds__(MAXT, (MAXT <= 256 ? ((OPT && !EXTRAS) ? 3 : MWRT_MIN_WAVES) : 1))
 k_tb_fused(const FusedArgs A) {
-  static_assert(NFC % NFK == 0, "NFC must be a multiple of NFK");
-  constexpr int NPASS = NFC / NFK;
+  constexpr int NPASS = (NFC + NFK - 1) / NFK;             // the last pass may hold fewer rows (14 = 8 + 6)
+  static_assert(NPASS <= 2, "LaunchGeom carries the split of two passes");
   extern __shared__ __attribute__((aligned(16))) double lds[];     // 16-B base: wide ds_read stays aligned (guide G17)
   const int tid = threadIdx.x;
   const int lane = tid & (WAVE - 1);
@@ -1090,9 +1121,14 @@ k_tb_fused(const FusedArgs A) {
 
   double* tau = lds;                                     // [NFK][ld] zenith layer optical depth (wet+dry)
   double* bof = tau + (size_t)NFK * ld;                  // [NFK][ld] Planck function B(T_i, f_j)
-  double* part = bof + (size_t)NFK * ld;                 // [NFK*nang*nseg][3] segment partials (B, T, sum tau)
-  double* scratch = part + (size_t)3 * NFK * nang * A.g.nseg;   // [16] block_sum scratch
+  double* part = bof + (size_t)NFK * ld;                 // [pairs*nseg][2] segment partials (B, T)
+  double* scratch = part + (size_t)A.g.npart;            // [16] block_sum scratch
   double* edge = scratch + 16;                           // [nwaves][2*NFC] last lane of each wave
+  constexpr int GRP = 16;                                // levels per group of the layer-tau maxima
+  const int ngrp = nthreads / GRP;
+  float* gmax = (float*)(edge + (size_t)nwaves * 2 * NFC);   // [NFK][ngrp] largest zenith layer tau of 16 levels of a row
+  int* wcnt = (int*)(gmax + (size_t)NFK * ngrp);          // [nwaves] thin work items per wave
+  int* perm = wcnt + nwaves;                              // [nthreads] work items, thin ones first
   __shared__ int s_flag;
   __shared__ double sfq[3 * NFC + 2];                     // {f, f^2} per slot, {fmin, fmax}, N2 fdep per slot (broadcast reads)
 
@@ -1167,11 +1203,13 @@ k_tb_fused(const FusedArgs A) {
     const bool has_prev = active && tid > 0;
 #pragma unroll
     for (int j = 0; j < NFC; ++j) {
+#pragma clang fp contract(off)               // wet * dz + dry * dz rounds the same way in every instantiation
       double pw = __shfl_up(awet[j], 1, WAVE);
       double pd = __shfl_up(adry[j], 1, WAVE);
       if (seam) { pw = edge[(wave - 1) * 2 * NFC + j]; pd = edge[(wave - 1) * 2 * NFC + NFC + j]; }
-      const double twj = has_prev ? layer_value(awet[j], pw, neg) * dz : 0.0;
-      const double tdj = has_prev ? layer_value(adry[j], pd, neg) * dz : 0.0;
+      const double lw = layer_value(awet[j], pw, neg, has_prev), ld_ = layer_value(adry[j], pd, neg, has_prev);
+      const double twj = has_prev ? lw * dz : 0.0;
+      const double tdj = has_prev ? ld_ * dz : 0.0;
       if constexpr (EXTRAS) { tw[j] = twj; td[j] = tdj; }
       else td[j] = twj + tdj;
     }
@@ -1208,8 +1246,9 @@ k_tb_fused(const FusedArgs A) {
         const double pl = has_below ? row(j)[tid - 1] : 0.0;
         const double ai = (deni > 0.0) ? CLOUD_KICE * f * deni : 0.0;
         const double pc = (deni_prev > 0.0) ? CLOUD_KICE * f * deni_prev : 0.0;
-        const double tlj = has_below ? layer_value<false>(al, pl, neg) * dz : 0.0;
-        const double tij = has_below ? layer_value<false>(ai, pc, neg) * dz : 0.0;
+        const double ll = layer_value<false>(al, pl, neg, has_below), li = layer_value<false>(ai, pc, neg, has_below);
+        const double tlj = has_below ? ll * dz : 0.0;
+        const double tij = has_below ? li * dz : 0.0;
         if constexpr (CLOUD_ROWS) { tl[j] = tlj; tci[j] = tij; }
         else td[j] = (td[j] + tij) + tlj;
       }
@@ -1239,7 +1278,6 @@ k_tb_fused(const FusedArgs A) {
     }
     want_tau = (A.tauwet != nullptr) || (A.taudry != nullptr) || (A.tauliq != nullptr) || (A.tauice != nullptr);
   }
-  const int nseg = A.g.nseg, seglen = A.g.seglen;
 
   // ---- phase K2: slant-path RTE (RTEquation.planck, from_sat = False [EXT]), NFK rows at a time ----
 #pragma unroll
@@ -1247,16 +1285,29 @@ k_tb_fused(const FusedArgs A) {
     const int nfk = min(NFK, nfc - h * NFK);            // frequencies live in this pass (uniform)
     if (nfk <= 0) break;
     if (h > 0) __syncthreads();                          // previous pass has finished reading LDS
-    if (active) {
+    const int nseg = A.g.nseg[h], seglen = A.g.seglen[h];
+    const int npairs = nfk * nang;
+    const int items = (MWRT_ABLATE & 8) ? 0 : npairs * nseg;
+    // wave-uniform: this pass deals its work items to the lanes thin ones first (see below)
+    const bool sorted = !(OPT && A.amf) && items <= nthreads && seglen >= K2_SORT_MIN_SEGLEN;
+    {
       const double hkt = fdiv(hk, ti);                  // h / (k T) per GHz
 #pragma unroll
       for (int jj = 0; jj < NFK; ++jj) {
         const int j = h * NFK + jj;
-        double tz = td[j];
-        if constexpr (EXTRAS) tz = tw[j] + td[j];
-        if constexpr (CLOUD_ROWS) tz = (tz + tci[j]) + tl[j];
-        tau[jj * ld + tid] = tz;
-        bof[jj * ld + tid] = planck_b(sfq[2 * j] * hkt);
+        if (j < NFC) {
+          double tz = td[j];
+          if constexpr (EXTRAS) tz = tw[j] + td[j];
+          if constexpr (CLOUD_ROWS) tz = (tz + tci[j]) + tl[j];
+          const double bz = planck_b(sfq[2 * j] * hkt);
+          if (active) { tau[jj * ld + tid] = tz; bof[jj * ld + tid] = bz; }
+          // largest layer value of each group of 16 levels (rounded up): decides once per work item whether
+          // every layer of its segment is thin at its airmass
+          if (sorted) {
+            const float m = row16_max(active ? (float)tz * 1.0000005f : 0.0f);
+            if ((lane & (GRP - 1)) == 0) gmax[jj * ngrp + tid / GRP] = m;
+          }
+        }
       }
     }
     // optional zenith opacity sums (tauwet / taudry columns); deterministic order
@@ -1266,11 +1317,13 @@ k_tb_fused(const FusedArgs A) {
       if (want_tau && !rays) {
 #pragma unroll
         for (int jj = 0; jj < NFK; ++jj) {
-          swet[jj] = block_sum(tw[h * NFK + jj], scratch, tid, nthreads);
-          sdry[jj] = block_sum(td[h * NFK + jj], scratch, tid, nthreads);
+          constexpr int JL = NFC - 1;
+          const int j = min(h * NFK + jj, JL);               // rows past the chunk repeat the last one (never read)
+          swet[jj] = block_sum(tw[j], scratch, tid, nthreads);
+          sdry[jj] = block_sum(td[j], scratch, tid, nthreads);
           if constexpr (OPT) {
-            sliq[jj] = block_sum(tl[h * NFK + jj], scratch, tid, nthreads);
-            sice[jj] = block_sum(tci[h * NFK + jj], scratch, tid, nthreads);
+            sliq[jj] = block_sum(tl[j], scratch, tid, nthreads);
+            sice[jj] = block_sum(tci[j], scratch, tid, nthreads);
           } else {
             sliq[jj] = 0.0; sice[jj] = 0.0;
           }
@@ -1289,7 +1342,7 @@ k_tb_fused(const FusedArgs A) {
 #pragma unroll
             for (int jj = 0; jj < NFK; ++jj) {
               const int j = h * NFK + jj;
-              tau[jj * ld + tid] = sp == 0 ? tw[j] : sp == 1 ? td[j] : sp == 2 ? tl[j] : tci[j];
+              if (j < NFC) tau[jj * ld + tid] = sp == 0 ? tw[j] : sp == 1 ? td[j] : sp == 2 ? tl[j] : tci[j];
             }
           }
           __syncthreads();
@@ -1306,20 +1359,48 @@ k_tb_fused(const FusedArgs A) {
 #pragma unroll
           for (int jj = 0; jj < NFK; ++jj) {
             const int j = h * NFK + jj;
-            tau[jj * ld + tid] = ((tw[j] + td[j]) + tci[j]) + tl[j];
+            if (j < NFC) tau[jj * ld + tid] = ((tw[j] + td[j]) + tci[j]) + tl[j];
           }
         }
       }
     }
     __syncthreads();
 
-    const int npairs = nfk * nang;
-    const int items = (MWRT_ABLATE & 8) ? 0 : npairs * nseg;
-    for (int it = tid; it < items; it += nthreads) {
-      const int seg = it / npairs;
-      const int pr = it - seg * npairs;
-      const int jj = pr / nang;
-      const int a = pr - jj * nang;
+    // Work item = (pair, level segment).  A layer is thin when tau * airmass <= 1/8: an item whose whole
+    // segment is thin takes the division-free step.  The choice is per WAVE, so the items are dealt to the lanes
+    // thin ones first (ballot ranks + one pass through LDS): at most one wave mixes both kinds and runs the
+    // general step for all its lanes.  The maxima that decide it are per 16 levels of a row (gmax).
+    int nthin_all = 0;
+    if (sorted) {
+      const bool mine = tid < items;
+      const int it = mine ? tid : 0;
+      const int pr = it / nseg, seg = it - pr * nseg;
+      const int jj = pr / nang, a = pr - jj * nang;
+      const int lo = 1 + seg * seglen, hi = min(lo + seglen, nlev);
+      float gm = 0.0f;
+      for (int g = lo / GRP; g <= (hi - 1) / GRP; ++g) gm = fmaxf(gm, gmax[jj * ngrp + g]);
+      // a NaN airmass (its rows come out NaN either way) counts as thin
+      const bool thin = mine && !((double)gm * cam[a] > EXP_SMALL_X);
+      const unsigned long long bal = __ballot(thin);
+      const int rank = __popcll(bal & ((1ull << lane) - 1ull));
+      if (lane == 0) wcnt[wave] = __popcll(bal);
+      __syncthreads();
+      int before = 0, nthin = 0;
+      for (int w = 0; w < nwaves; ++w) { const int c = wcnt[w]; nthin += c; if (w < wave) before += c; }
+      if (mine) perm[thin ? before + rank : nthin + tid - (before + rank)] = (a << 11) | (jj << 7) | seg;
+      nthin_all = nthin;
+      __syncthreads();
+    }
+    for (int it0 = tid; it0 < items; it0 += nthreads) {
+      int seg, jj, a;
+      if (sorted) {
+        const int key = perm[it0];
+        seg = key & 127; jj = (key >> 7) & 15; a = key >> 11;
+      } else {
+        const int pr = it0 / nseg;
+        seg = it0 - pr * nseg; jj = pr / nang; a = pr - jj * nang;
+      }
+      const int it = (jj * nang + a) * nseg + seg;
       const double am = cam[a];
       const int lo = 1 + seg * seglen;
       const int hi = min(lo + seglen, nlev);
@@ -1327,36 +1408,78 @@ k_tb_fused(const FusedArgs A) {
       const double* bj = bof + jj * ld;
       const double* fr = nullptr;
       if constexpr (OPT) fr = A.amf ? A.amf + (pin * nang + a) * nlev : nullptr;
-      double T = 1.0, B = 0.0, S = 0.0;
+      double T = 1.0, B = 0.0;
       double bprev = (lo < nlev) ? bj[lo - 1] : 0.0;
-      for (int i = lo; i < hi; ++i) {
-        const double tl = tj[i] * ((OPT && fr) ? fr[i] : am);
-        const double E = __all(fabs(tl) <= EXP_SMALL_X) ? fexp_small(-tl) : fexp(-tl);
-        const double bi = bj[i];
-        const double lay = fdiv1(__builtin_fma(bi, E, bprev), 1.0 + E);
-        B = __builtin_fma(lay * T, 1.0 - E, B);
-        T *= E;
-        S += tl;
-        bprev = bi;
+      if (!sorted) {
+        // short segments, several rounds, or ray-traced path factors (they vary with the level): thin or not is
+        // voted per step
+        for (int i = lo; i < hi; ++i) {
+          const double tl = tj[i] * ((OPT && fr) ? fr[i] : am);
+          const double E = __all(fabs(tl) <= EXP_SMALL_X) ? fexp_small(-tl) : fexp(-tl);
+          const double bi = bj[i];
+          const double lay = fdiv1(__builtin_fma(bi, E, bprev), 1.0 + E);
+          B = __builtin_fma(lay * T, 1.0 - E, B);
+          T *= E;
+          bprev = bi;
+        }
+      } else if (__all(it0 < nthin_all)) {
+        // boflay (1 - E) = (B_{i-1} + B_i E) (1 - E)/(1 + E) = (B_{i-1} + B_i E) tanh(tau/2)
+        auto step = [&](double tz, double bi) {
+          const double tl = tz * am;
+          const double E = fexp_small(-tl);
+          const double th = ftanh_half_small(tl);
+          B = __builtin_fma(__builtin_fma(bi, E, bprev) * T, th, B);
+          T *= E;
+          bprev = bi;
+        };
+        // two layers per trip, the next trip's rows already in flight (index hi <= nlev is inside the padded row)
+        int i = lo;
+        double t0 = (i < hi) ? tj[i] : 0.0, b0 = (i < hi) ? bj[i] : 0.0;
+        for (; i + 1 < hi; i += 2) {
+          const double t1 = tj[i + 1], b1 = bj[i + 1];
+          const double t2 = tj[i + 2], b2 = bj[i + 2];
+          step(t0, b0); step(t1, b1);
+          t0 = t2; b0 = b2;
+        }
+        if (i < hi) step(t0, b0);
+      } else {
+        auto step = [&](double tz, double bi) {
+          const double tl = tz * am;
+          const double E = fexp(-tl);
+          const double lay = fdiv1(__builtin_fma(bi, E, bprev), 1.0 + E);
+          B = __builtin_fma(lay * T, 1.0 - E, B);
+          T *= E;
+          bprev = bi;
+        };
+        int i = lo;
+        double t0 = (i < hi) ? tj[i] : 0.0, b0 = (i < hi) ? bj[i] : 0.0;
+        for (; i + 1 < hi; i += 2) {
+          const double t1 = tj[i + 1], b1 = bj[i + 1];
+          const double t2 = tj[i + 2], b2 = bj[i + 2];
+          step(t0, b0); step(t1, b1);
+          t0 = t2; b0 = b2;
+        }
+        if (i < hi) step(t0, b0);
       }
-      part[3 * it + 0] = B; part[3 * it + 1] = T; part[3 * it + 2] = S;
+      part[2 * it + 0] = B; part[2 * it + 1] = T;
     }
     __syncthreads();
     for (int pr = tid; pr < npairs; pr += nthreads) {
       const int jj = pr / nang;
       const int a = pr - jj * nang;
       const int j = h * NFK + jj;
-      double B = 0.0, T = 1.0, S = 0.0;
+      double B = 0.0, T = 1.0;
       for (int sg = 0; sg < nseg; ++sg) {
-        const double* q = part + 3 * (sg * npairs + pr);
+        const double* q = part + 2 * (pr * nseg + sg);
         B = __builtin_fma(T, q[0], B);
         T *= q[1];
-        S += q[2];
       }
       const double hvk = cfrq[jbase + j] * hk;
       double boftotl, boftmr;
-      if (S < TAUMAX) {
-        const double ex = fexp(-S);
+      // T is exp(-tauprof) of the whole path; pyrtlib's "tauprof < 125" cut is T > exp(-125) (beyond it the
+      // cosmic term is 1e-54 of B either way)
+      if (T > TRANS_MIN) {
+        const double ex = T;
         const double bbg = fdiv(1.0, fexp(fdiv(hvk, M->t_cosmic)) - 1.0);
         boftotl = __builtin_fma(bbg, ex, B);
         boftmr = EXTRAS ? fdiv(B, 1.0 - ex) : 0.0;

@@ -128,7 +128,9 @@ def test_nan_in_nan_out(gpu_ctx):
         for k in ("tbatm", "tmr", "tauwet", "taudry"):
             assert np.isnan(ex[k][:, bad, :]).all() and not np.isnan(ex[k][:, keep, :]).any()
         assert not np.isnan(ex["taulay"]).any()                # zenith layer depths carry no angle
-        assert np.array_equal(tb[:, keep, :], clean[:, keep, :])
+        # the surviving angles: same numbers (to the elevation-mates note of include/mwrt.h -- with 4.2 degrees
+        # gone a wave may take the thin-layer form it could not take before)
+        assert np.abs(tb[:, keep, :] - clean[:, keep, :]).max() <= 1e-10
     a = np.full(7, np.nan)
     tb, valid = gpu_ctx.tb_batch("R24", P["z"], P["p"], P["t"], P["rh"], pr.HATPRO_FRQS, a)
     assert np.isnan(tb).all() and (valid == 0).all()
@@ -857,7 +859,7 @@ def test_ray_tracing_matches_oracle(gpu_ctx, name):
         assert np.abs(tb[i].ravel() - ref["tbtotal"]).max() <= TOL_K, i
         for k in ("tauwet", "taudry"):
             assert np.allclose(ex[k][i].ravel(), ref[k], rtol=1e-9, atol=1e-14), (k, i)
-    assert np.array_equal(tb[:, 0], flat[:, 0])                          # zenith: the same path
+    assert np.abs(tb[:, 0] - flat[:, 0]).max() <= 1e-10                   # zenith: the same path (per-step vs per-item layer form)
     assert (tb[:, -1, :7] < flat[:, -1, :7] - 1.0).all()                 # 4.2 deg, K band: shorter path, > 1 K colder
     # cloud + rays together, and a NaN elevation blanks only its own rows
     lwc, iwc = cloud_profiles(P, 8)
