@@ -1066,3 +1066,27 @@ def test_fine_grid_path_in_several_profile_batches(gpu_ctx, monkeypatch):
     assert np.array_equal(np.isnan(one), np.isnan(many)) and np.array_equal(np.nan_to_num(one), np.nan_to_num(many))
     ref = lo.tb_cloud_rte(sp.get_model("R17"), P["z"][33], P["p"][33], P["t"][33], P["rh"][33], frq[::50], ang)["tbtotal"]
     assert np.abs(many[33][:, ::50].ravel() - ref).max() <= TOL_K
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("nlev,ang", [(180, pr.BENCH_ELEVATIONS_7), (180, pr.REFERENCE_ELEVATIONS), (180, np.array([90.0, 2.0])),
+                                      (97, np.linspace(90.0, 3.0, 23)), (40, pr.BENCH_ELEVATIONS_7), (500, pr.BENCH_ELEVATIONS_7)],
+                         ids=["7", "10", "steep", "23-of-97", "short-segments", "tall"])
+def test_layer_step_forms_agree(gpu_ctx, nlev, ang):
+    """K2's thin-layer step (tanh series, items dealt thin-first), its general step and the per-step vote it falls
+    back to (short segments, several rounds) are the same quantity: one call with every elevation against one call
+    per elevation (which takes the fallback), to the 1e-10 K of include/mwrt.h's elevation-mates note; and a tight
+    bound against the oracle.  Thick (58 GHz at 2 degrees) and thin (31.4 GHz zenith) layers sit in the same call."""
+    P = pr.synthetic_profiles(6, 91, nlev=nlev)
+    P["rh"][2] = np.minimum(1.0, P["rh"][2] * 3.0)           # a humid column: thicker K-band layers
+    P["rh"][3] *= 0.02                                        # and a dry one
+    frq = pr.HATPRO_FRQS
+    tb, valid = gpu_ctx.tb_batch("R24", P["z"], P["p"], P["t"], P["rh"], frq, ang)
+    assert (valid == 1).all()
+    for k, a in enumerate(ang):
+        one, v1 = gpu_ctx.tb_batch("R24", P["z"], P["p"], P["t"], P["rh"], frq, np.array([a]))
+        assert np.abs(one[:, 0] - tb[:, k]).max() <= 1e-10, a
+    m = sp.get_model("R24")
+    for i in (0, 2, 3):
+        ref = lo.tb_cloud_rte(m, P["z"][i], P["p"][i], P["t"][i], P["rh"][i], frq, ang)["tbtotal"]
+        assert np.abs(tb[i].ravel() - ref).max() <= 2e-9, i
