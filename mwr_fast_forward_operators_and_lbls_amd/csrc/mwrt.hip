@@ -169,7 +169,7 @@ size_t fused_lds_bytes(int nfc, const LaunchGeom& g, int /*nang*/, int threads) 
 }
 
 // K2 split for a chunk width, shrunk until the workgroup's LDS fits; false if it cannot
-bool plan_fused(const mwrt_context* c, int nfc, int nlev, int nf, int nang, LaunchGeom* g, size_t* lds);
+bool plan_fused(const mwrt_context* c, int nfc, int nlev, int nf, int nang, LaunchGeom* g, size_t* lds, int threads = 0);
 
 int upload_small(mwrt_context* c, ParamCache& cache, const double* src, int n, const double** dev) {
   HIP_TRY(cache.get(src, n, c->stream, dev));
@@ -218,10 +218,13 @@ void timing_end(mwrt_context* c, hipStream_t st) {
 }
 
 int launch_fused(mwrt_context* c, int nfc, FusedArgs a, int64_t nprof, hipStream_t st, int variant) {
-  const int threads = ((a.nlev + WAVE - 1) / WAVE) * WAVE;
+  int threads = ((a.nlev + WAVE - 1) / WAVE) * WAVE;
+  // The RTE-from-absorption kernel is light on registers (4 waves per SIMD fit): a fourth wave that holds no
+  // level still takes its share of the (frequency, angle, segment) items, 90 serial layer steps instead of 120
+  if (variant == FUSED_FROM_ALPHA && threads < 256 && a.nang > 1) threads = 256;
   const int nchunks = (a.nf + nfc - 1) / nfc;
   size_t lds = 0;
-  if (!plan_fused(c, nfc, a.nlev, a.nf, a.nang, &a.g, &lds))
+  if (!plan_fused(c, nfc, a.nlev, a.nf, a.nang, &a.g, &lds, threads))
     return fail(MWRT_ERR_UNSUPPORTED, "LDS budget exceeded (nlev x nang too large)");
   dim3 grid((unsigned)nprof /* = nmodels x profiles */, (unsigned)nchunks), block(threads);
   // valid[] = 1 is written by the kernel itself when one workgroup owns the profile; with several
@@ -256,8 +259,8 @@ int launch_absorb(mwrt_context* c, int nfc, const AbsorbArgs& a, int64_t nprof, 
   return MWRT_OK;
 }
 
-bool plan_fused(const mwrt_context* c, int nfc, int nlev, int nf, int nang, LaunchGeom* g, size_t* lds) {
-  const int threads = ((nlev + WAVE - 1) / WAVE) * WAVE;
+bool plan_fused(const mwrt_context* c, int nfc, int nlev, int nf, int nang, LaunchGeom* g, size_t* lds, int threads) {
+  if (threads <= 0) threads = ((nlev + WAVE - 1) / WAVE) * WAVE;
   *g = plan_k2(nlev, nfc, nf, nang, threads);
   *lds = fused_lds_bytes(nfc, *g, nang, threads);
   while (*lds > (size_t)c->lds_max && (g->nseg[0] > 1 || g->nseg[1] > 1)) {     // shrink the partials if LDS is short

@@ -1149,6 +1149,9 @@ k_tb_fused(const FusedArgs A) {
   __syncthreads();
 
   const bool active = tid < nlev;
+  // a wave beyond the top level (the RTE-from-absorption launch adds one for the K2 work items) holds no level:
+  // it skips the per-level phases wave-uniformly and only meets the barriers
+  const bool wave_live = wave * WAVE < nlev;
   const int64_t off = pin * nlev + (active ? tid : 0);
   const double zi = A.z[off], ti = A.t[off];
   const double pi = ALPHA ? 0.0 : A.p[off], rhi = ALPHA ? 0.0 : A.rh[off];
@@ -1156,12 +1159,17 @@ k_tb_fused(const FusedArgs A) {
   double awet[NFC], adry[NFC];
   if constexpr (ALPHA) {
     bool bad = false;
+    if (wave_live) {
 #pragma unroll
-    for (int j = 0; j < NFC; ++j) {
-      const int64_t o = (pin * A.nf + jbase + min(j, nfc - 1)) * nlev + (active ? tid : 0);     // 512-B rows per wave
-      awet[j] = A.awet_in[o];
-      adry[j] = A.adry_in[o];
-      bad = bad || isnan(awet[j]) || isnan(adry[j]);
+      for (int j = 0; j < NFC; ++j) {
+        const int64_t o = (pin * A.nf + jbase + min(j, nfc - 1)) * nlev + (active ? tid : 0);     // 512-B rows per wave
+        awet[j] = A.awet_in[o];
+        adry[j] = A.adry_in[o];
+        bad = bad || isnan(awet[j]) || isnan(adry[j]);
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < NFC; ++j) { awet[j] = 0.0; adry[j] = 0.0; }
     }
     if (active && bad) atomicOr(&s_flag, 1);
   }
@@ -1201,6 +1209,10 @@ k_tb_fused(const FusedArgs A) {
     const double dz = (active && tid > 0) ? ((zi - z0) - (A.z[off - 1] - z0)) : 0.0;
     const bool seam = (lane == 0) && (wave > 0);
     const bool has_prev = active && tid > 0;
+    if (!wave_live) {
+#pragma unroll
+      for (int j = 0; j < NFC; ++j) { td[j] = 0.0; if constexpr (EXTRAS) tw[j] = 0.0; }
+    } else
 #pragma unroll
     for (int j = 0; j < NFC; ++j) {
 #pragma clang fp contract(off)               // wet * dz + dry * dz rounds the same way in every instantiation
@@ -1290,7 +1302,7 @@ k_tb_fused(const FusedArgs A) {
     const int items = (MWRT_ABLATE & 8) ? 0 : npairs * nseg;
     // wave-uniform: this pass deals its work items to the lanes thin ones first (see below)
     const bool sorted = !(OPT && A.amf) && items <= nthreads && seglen >= K2_SORT_MIN_SEGLEN;
-    {
+    if (wave_live) {
       const double hkt = fdiv(hk, ti);                  // h / (k T) per GHz
 #pragma unroll
       for (int jj = 0; jj < NFK; ++jj) {
