@@ -1090,8 +1090,9 @@ __device__ __forceinline__ void blank_outputs(const FusedArgs& A, int64_t prof, 
 // NFK = frequencies per K2 pass (rows of tau / B kept in LDS at a time): NFC = NPASS * NFK.
 // Keeping only NFK rows resident holds the workgroup under 40 KB of LDS, so FOUR 192-thread
 // workgroups (12 waves = 3 per SIMD) fit a CU and a 1000-profile batch is one resident round.
-// (the cloud / ray-tracing TB variant lands one register above the 3-waves-per-SIMD step on its own: it is
-// asked for 3 waves explicitly)
+// (the TB-only variants are pinned to 3 waves per SIMD -- the clear-sky one sits at 161 of 168 VGPRs on its own and
+// twelve more cost a third of the throughput; the cloud / ray-tracing one lands one register above the step and
+// spills two; the RTE-from-absorption variant is pinned to the 4 waves its 256-thread launch relies on)
 #ifndef MWRT_MIN_WAVES
 #define MWRT_MIN_WAVES 1
 #endif
@@ -1099,7 +1100,7 @@ __device__ __forceinline__ void blank_outputs(const FusedArgs& A, int64_t prof, 
 // evaluated -- the two-kernel K1 -> alpha -> K2 form of the fine-grid configuration, and the entry for callers
 // who bring their own absorption.
 template <int NFC, int NFK, int MAXT, bool OPT = false, bool EXTRAS = false, bool ALPHA = false>
-__global__ void __launch_bounds__(MAXT, (MAXT <= 256 ? ((OPT && !EXTRAS) ? 3 : MWRT_MIN_WAVES) : 1))
+__global__ void __launch_bounds__(MAXT, (MAXT <= 256 ? (EXTRAS ? MWRT_MIN_WAVES : (ALPHA ? 4 : 3)) : 1))
 k_tb_fused(const FusedArgs A) {
   constexpr int NPASS = (NFC + NFK - 1) / NFK;             // the last pass may hold fewer rows (14 = 8 + 6)
   static_assert(NPASS <= 2, "LaunchGeom carries the split of two passes");
