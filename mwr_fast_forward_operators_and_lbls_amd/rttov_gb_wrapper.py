@@ -15,7 +15,11 @@ Profile block (per profile, levels TOP -> GROUND as in the reference data set):
 RTTOV-gb profiles carry no geometric height: it is rebuilt hydrostatically from (p, T, q) above
 the station height, and humidity converts as e = ppmv * p / 1e6 (the reference's own
 ``rh2ppmv`` / ``ppmv2rh``, preprocessing4all.py:124-136) with pyrtlib's Goff-Gratch e_s.
-Jacobians (the K-matrix block the reference also parses) are not produced.
+The K-matrix block the reference also parses (:286-300: per channel a header of three lines, then one row
+``level p dTB/dT dTB/dppmv dTB/dliq`` per level) is produced by ``jacobians`` (central / forward differences
+through the batched operator) and written / read by ``format_jacobians`` / ``parse_jacobians``.  Liquid water
+enters through the cloud-liquid opt-in of the LBL operator (``clear_sky=False``; the reference itself runs RTTOV-gb
+with ``clear_sky_bool=True``, :82-86, so the default here is clear sky too).
 """
 from __future__ import annotations
 
@@ -102,8 +106,11 @@ def to_lbl_inputs(profiles: Iterable[dict]):
     return (np.array(Z), np.array(P), np.array(T), np.array(RH), np.array(ELEV))
 
 
-def simulate(profiles: List[dict], model: str = "R24", frqs=HATPRO_FRQS):
+def simulate(profiles: List[dict], model: str = "R24", frqs=HATPRO_FRQS, clear_sky: bool = True):
     """TBs, surface-to-space transmittance and level-to-surface transmittances for parsed profiles.
+
+    ``clear_sky=False`` feeds each profile's ``liquid`` column [kg/kg] to the operator's cloud-liquid opt-in
+    (density conversion as upstream, derive_cloud_water.py:88-92).
 
     Returns dict: ``tbs`` [nprof][nchan], ``tau_total`` [nprof][nchan] (transmittance, slant path),
     ``tau_levels`` [nprof][nlev][nchan] (level -> surface transmittance, levels TOP -> GROUND like the
@@ -115,21 +122,31 @@ def simulate(profiles: List[dict], model: str = "R24", frqs=HATPRO_FRQS):
     trans = np.full((nprof, len(frqs)), np.nan)
     trans_lev = np.full((nprof, nlev, len(frqs)), np.nan)
     valid = np.zeros(nprof, dtype=np.uint8)
+    denliq = None
+    if not clear_sky:
+        from .pyrtlib_processing import cloud_density_g_m3
+        q = np.array([np.asarray(pr["liquid"], dtype=float)[::-1] for pr in profiles])
+        denliq = cloud_density_g_m3(q, p, t)
     for ang in np.unique(elev):                             # profiles sharing an elevation go in one launch
         idx = np.nonzero(elev == ang)[0]
         args = (tables, z[idx], p[idx], t[idx], rh[idx], np.asarray(frqs, dtype=float), np.array([ang]))
-        tb, v, ex = _native.default_context().tb_batch(*args, extras=True)
+        kw = {} if denliq is None else {"denliq": denliq[idx]}
+        tb, v, ex = _native.default_context().tb_batch(*args, extras=True, **kw)
         am = 1.0 / np.sin(ang * np.pi / 180)
         lay = ex["taulay"] * am                              # [n][nf][nlev] slant layer optical depth, ground -> top
         cum = np.cumsum(lay, axis=2)                         # surface -> level i
         tbs[idx] = tb[:, 0, :]
-        trans[idx] = np.exp(-(ex["tauwet"][:, 0, :] + ex["taudry"][:, 0, :]))
+        tot = ex["tauwet"][:, 0, :] + ex["taudry"][:, 0, :]
+        if denliq is not None:
+            tot = tot + ex["tauliq"][:, 0, :]
+        trans[idx] = np.exp(-tot)
         trans_lev[idx] = np.exp(-cum).transpose(0, 2, 1)[:, ::-1, :]
         valid[idx] = v
     return {"tbs": tbs, "tau_total": trans, "tau_levels": trans_lev, "valid": valid}
 
 
-def jacobians(profile: dict, model: str = "R24", frqs=HATPRO_FRQS, dT: float = 0.05, rel_q: float = 0.01):
+def jacobians(profile: dict, model: str = "R24", frqs=HATPRO_FRQS, dT: float = 0.05, rel_q: float = 0.01,
+              liquid: bool = False, d_liq: float = 1e-5):
     """Brute-force K-matrix of one profile by central differences through the batched operator.
 
     RTTOV-gb's K run (the block the reference parses at RTTOV_gb_processing.py:264-283) returns
@@ -137,7 +154,12 @@ def jacobians(profile: dict, model: str = "R24", frqs=HATPRO_FRQS, dT: float = 0
     ``4*nlev`` perturbed copies of the profile costs about as much as one profile.  Heights are
     rebuilt hydrostatically for every perturbed copy (as RTTOV-gb does internally).
 
-    Returns ``(dTB_dT [nlev][nchan] in K/K, dTB_dq [nlev][nchan] in K/ppmv)``, levels TOP -> GROUND.
+    Returns ``(dTB_dT [nlev][nchan] in K/K, dTB_dq [nlev][nchan] in K/ppmv)``, levels TOP -> GROUND; with
+    ``liquid=True`` a third array ``dTB_dliq`` in K per kg/kg (the reference's ``Jacobian_liq_RTTOV_gb``,
+    :426-432): forward difference of ``d_liq`` on top of the profile's own liquid column, through the cloud-liquid
+    opt-in (so the T and q columns are then taken in the presence of that liquid as well).  pyrtlib's layer rule
+    for cloud empties a layer with a cloud-free end (zeroflg = False), so a level's liquid acts only together with a
+    cloudy neighbour: the column is exactly zero in clear air away from cloud.
     """
     nlev = len(profile["p"])
     copies = []
@@ -153,14 +175,59 @@ def jacobians(profile: dict, model: str = "R24", frqs=HATPRO_FRQS, dT: float = 0
             c["ppmv"] = profile["ppmv"].copy()
             c["ppmv"][lv] *= (1.0 + sign * rel_q)
             copies.append(c)
-    res = simulate(copies, model, frqs)
+    if liquid:
+        copies.append(dict(profile))
+        for lv in range(nlev):
+            c = dict(profile)
+            c["liquid"] = np.asarray(profile["liquid"], dtype=float).copy()
+            c["liquid"][lv] += d_liq
+            copies.append(c)
+    res = simulate(copies, model, frqs, clear_sky=not liquid)
     if not (res["valid"] == 1).all():
         raise ValueError("a perturbed profile was rejected")
     tb = res["tbs"]
     d_t = (tb[0:nlev] - tb[nlev:2 * nlev]) / (2.0 * dT)
     dq = 2.0 * rel_q * profile["ppmv"][:, None]
     d_q = (tb[2 * nlev:3 * nlev] - tb[3 * nlev:4 * nlev]) / np.where(dq != 0.0, dq, np.nan)
-    return d_t, d_q
+    if not liquid:
+        return d_t, d_q
+    d_l = (tb[4 * nlev + 1:5 * nlev + 1] - tb[4 * nlev]) / d_liq
+    return d_t, d_q, d_l
+
+
+def format_jacobians(p_levels, d_t, d_q, d_l=None) -> str:
+    """K-matrix text in the layout the reference's parser walks (RTTOV_gb_processing.py:286-300): per channel a
+    line holding ``Channel        <n>``, two more header lines, then one row per level
+    ``level  p  dTB/dT  dTB/dppmv  dTB/dliq`` (levels TOP -> GROUND)."""
+    nlev, nch = d_t.shape
+    if d_l is None:
+        d_l = np.zeros_like(d_t)
+    out = []
+    for c in range(nch):
+        out.append(f" Channel        {c + 1}\n")
+        out.append("  Level   Pressure      Temperature        WV (ppmv)        Liquid (kg/kg)\n")
+        out.append("            (hPa)        jacobian (K/K)   jacobian (K/ppmv)  jacobian (K/(kg/kg))\n")
+        for lv in range(nlev):
+            out.append(f"{lv + 1:5d} {p_levels[lv]:10.4f} {d_t[lv, c]:18.10E} {d_q[lv, c]:18.10E} {d_l[lv, c]:18.10E}\n")
+        out.append("\n")
+    return "".join(out)
+
+
+def parse_jacobians(text: str, nlevels: int, nchan: int = 14):
+    """Reader for ``format_jacobians`` with the reference's own walk (:286-300): ``[nlev][nchan][4]`` =
+    (p, dTB/dT, dTB/dppmv, dTB/dliq)."""
+    jac = np.full((nlevels, nchan, 4), np.nan)
+    lines = text.splitlines()
+    i = 0
+    while i < len(lines):
+        if "Channel        " in lines[i]:
+            ch = int(lines[i].split("Channel")[-1]) - 1
+            for j, ln in enumerate(lines[i + 3:i + 3 + nlevels]):
+                jac[j, ch, :] = [float(x) for x in ln.split()[1:]]
+            i += nlevels + 3
+        else:
+            i += 1
+    return jac
 
 
 def format_output(result: dict) -> str:

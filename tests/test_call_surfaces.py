@@ -109,3 +109,73 @@ def test_finite_difference_jacobians(oracle_ctx):
         z, p, t, rh, _ = rw.to_lbl_inputs([q])
         tbs.append(lo.tb_cloud_rte(sp.get_model("R98"), z[0], p[0], t[0], rh[0], rw.HATPRO_FRQS, np.array([90.0]))["tbtotal"])
     assert np.allclose(d_t[lv], (tbs[0] - tbs[1]) / 0.1, atol=1e-8)
+
+
+def test_liquid_jacobian_and_k_matrix_text(oracle_ctx):
+    """The third K-matrix column of the reference's RTTOV-gb parser (RTTOV_gb_processing.py:286-300, :426-432):
+    dTB/dliq through the cloud-liquid opt-in, and the text block in the layout that parser walks."""
+    text, _ = rttov_text(nprof=1, nlev=24, elevs=(90.0,))
+    prof = rw.parse_profiles(text, 24)[0]
+    clear = rw.jacobians(prof, "R98", liquid=True)[2]
+    # pyrtlib's layer rule for cloud (a zero neighbour empties the layer) makes a lone cloudy level invisible
+    assert (clear == 0).all()
+    prof["liquid"] = np.zeros(24); prof["liquid"][14:20] = 1e-4    # a cloud over six levels (top -> ground indices)
+    d_t, d_q, d_l = rw.jacobians(prof, "R98", liquid=True)
+    assert d_l.shape == (24, 14) and np.isfinite(d_l).all()
+    # liquid emits against the cold sky in the window channels: warming inside the cloud and at its two edges,
+    # more at 31.4 GHz than at 25.44 GHz; nothing away from it
+    assert (d_l[13:21, :7] > 0).all() and (d_l[14:20, 6] > d_l[14:20, 3]).all()
+    assert (d_l[:13] == 0).all() and (d_l[21:] == 0).all()
+    assert d_l[14:20, 6].min() > 1e3                                # > 0.1 K per 1e-4 kg/kg and level
+    # one entry against a direct oracle difference
+    from mwr_fast_forward_operators_and_lbls_amd.pyrtlib_processing import cloud_density_g_m3
+    z, p, t, rh, _ = rw.to_lbl_inputs([prof])
+    lv = 16                                                          # top -> ground index; ground -> top is 23 - lv
+    liq0 = prof["liquid"][::-1].copy()
+    liq1 = liq0.copy(); liq1[23 - lv] += 1e-5
+    m = sp.get_model("R98")
+    base = lo.tb_cloud_rte(m, z[0], p[0], t[0], rh[0], rw.HATPRO_FRQS, np.array([90.0]),
+                           denliq=cloud_density_g_m3(liq0, p[0], t[0]))["tbtotal"]
+    pert = lo.tb_cloud_rte(m, z[0], p[0], t[0], rh[0], rw.HATPRO_FRQS, np.array([90.0]),
+                           denliq=cloud_density_g_m3(liq1, p[0], t[0]))["tbtotal"]
+    assert np.allclose(d_l[lv], (pert - base) / 1e-5, rtol=1e-7, atol=1e-4)
+    # with no liquid in the profile the T and q columns are the clear-sky ones
+    prof0 = dict(prof); prof0["liquid"] = np.zeros(24)
+    d_t0, d_q0 = rw.jacobians(prof0, "R98")
+    d_t1, d_q1, _ = rw.jacobians(prof0, "R98", liquid=True)
+    assert np.allclose(d_t1, d_t0, atol=1e-9) and np.allclose(d_q1, d_q0, atol=1e-12)
+    # text round trip, walked the way the reference walks it
+    txt = rw.format_jacobians(prof["p"], d_t, d_q, d_l)
+    assert txt.count("Channel        ") == 14
+    jac = rw.parse_jacobians(txt, 24)
+    assert np.allclose(jac[:, :, 0], prof["p"][:, None], atol=1e-4)
+    assert np.allclose(jac[:, :, 1], d_t, rtol=1e-9) and np.allclose(jac[:, :, 3], d_l, rtol=1e-9)
+    # the reference's own loop over that text (string accumulation, [3 : n_levels + 3], werte[1:])
+    n_levels = 24
+    got = np.zeros((n_levels, 14, 4))
+    sw, cnt, acc, ch_idx = False, 0, "", 0
+    for line in txt.splitlines(keepends=True):
+        if "Channel        " in line:
+            sw = True
+            ch_idx = int(line.split("Channel")[-1]) - 1
+        if sw and cnt < n_levels + 3:
+            cnt += 1
+            acc += line
+        elif sw:
+            for j, ln in enumerate(acc.split("\n")[3:n_levels + 3]):
+                got[j, ch_idx, :] = ln.split()[1:]
+            acc, sw, cnt = "", False, 0
+    assert np.allclose(got[:, :, 2], d_q, rtol=1e-9)
+
+
+def test_cloudy_rttov_surface(oracle_ctx):
+    """clear_sky=False: the liquid column of the profile text reaches the operator; transmittance includes it."""
+    text, _ = rttov_text(nprof=2, nlev=24, elevs=(90.0, 30.0))
+    profs = rw.parse_profiles(text, 24)
+    for pr_ in profs:
+        pr_["liquid"] = np.zeros(24); pr_["liquid"][-6:-3] = 2e-4
+    clear = rw.simulate(profs, "R98")
+    cloudy = rw.simulate(profs, "R98", clear_sky=False)
+    assert (cloudy["valid"] == 1).all()
+    assert (cloudy["tbs"][:, :7] > clear["tbs"][:, :7] + 1.0).all()           # K band: warmer under cloud
+    assert (cloudy["tau_total"] < clear["tau_total"]).all()

@@ -490,6 +490,13 @@ def test_jacobians_on_gpu(gpu_ctx):
     assert d_t.shape == (180, 14) and np.isfinite(d_t).all() and np.isfinite(d_q).all()
     assert abs(d_t[:, 13].sum() - 1.0) < 0.03                  # 58 GHz: temperature weights integrate to one
     assert (d_q[-60:, 0] > 0).all()                            # 22.24 GHz warms with boundary-layer humidity
+    # third K-matrix column (liquid water, through the cloud opt-in) on top of a cloud between levels 130 and 150
+    prof["liquid"] = np.zeros(180); prof["liquid"][130:150] = 2e-4
+    d_t2, d_q2, d_l = rw.jacobians(prof, "R24", liquid=True)
+    assert d_l.shape == (180, 14) and np.isfinite(d_l).all()
+    assert (d_l[130:150, :7] > 0).all() and (d_l[:129] == 0).all() and (d_l[151:] == 0).all()
+    jac = rw.parse_jacobians(rw.format_jacobians(prof["p"], d_t2, d_q2, d_l), 180)
+    assert np.allclose(jac[:, :, 3], d_l, rtol=1e-9)
 
 
 def test_argument_validation(gpu_ctx):
