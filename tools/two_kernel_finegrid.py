@@ -41,9 +41,11 @@ res = {}
 with torch.cuda.stream(st):
     for name, fn, mode in (("k1_direct", k1, 1), ("k1_absorb", k1, 0), ("k2_from_alpha", k2, 0), ("fused", fused, 1)):
         ctx.set_absorption_mode(mode)      # 1: every line at every frequency (k_absorb / plain fused kernel); 0: windowed K1
-        fn(); st.synchronize()
+        for _ in range(8):                  # past the GPU's clock ramp out of idle (cf. bench.py --spinup)
+            fn()
+        st.synchronize()
         ctx.set_timing(True)
-        for _ in range(3):
+        for _ in range(5):
             fn()
         st.synchronize()
         ms, n = ctx.timing_collect(); ctx.set_timing(False)
