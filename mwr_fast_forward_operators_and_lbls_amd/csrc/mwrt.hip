@@ -139,6 +139,13 @@ int plan_k2_pass(int nlev, int npairs, int threads) {
 // rows kept in LDS per K2 pass; a 14-wide chunk runs as passes of 8 and 6 rows, each with its own split
 int nfk_of(int /*nfc*/) { return 8; }
 
+unsigned magic_of(int d) { return d <= 1 ? 0u : (unsigned)((((uint64_t)1 << 32) + (uint64_t)d - 1) / (uint64_t)d); }
+void set_magics(LaunchGeom* g, int nang) {
+  g->magic_nseg[0] = magic_of(g->nseg[0]);
+  g->magic_nseg[1] = magic_of(g->nseg[1]);
+  g->magic_nang = magic_of(nang);
+}
+
 void set_pass(LaunchGeom* g, int h, int nlev, int ns) {
   g->nseg[h] = ns < 1 ? 1 : ns;
   g->seglen[h] = (nlev - 1 + g->nseg[h] - 1) / g->nseg[h];
@@ -153,6 +160,7 @@ LaunchGeom plan_k2(int nlev, int nfc, int nf, int nang, int threads) {
   set_pass(&g, 0, nlev, plan_k2_pass(nlev, rows0 * nang, threads));
   set_pass(&g, 1, nlev, rows1 > 0 ? plan_k2_pass(nlev, rows1 * nang, threads) : 1);
   g.npart = 2 * nang * std::max(rows0 * g.nseg[0], rows1 * g.nseg[1]);
+  set_magics(&g, nang);
   // row stride in doubles: odd multiple of 2 dwords keeps ds_read_b64 rows on distinct banks
   int ld = nlev + 1;
   if ((ld & 1) == 0) ld += 1;
@@ -269,6 +277,7 @@ bool plan_fused(const mwrt_context* c, int nfc, int nlev, int nf, int nang, Laun
     set_pass(g, 0, nlev, (g->nseg[0] + 1) / 2);
     set_pass(g, 1, nlev, (g->nseg[1] + 1) / 2);
     g->npart = 2 * nang * std::max(rows0 * g->nseg[0], rows1 * g->nseg[1]);
+    set_magics(g, nang);
     *lds = fused_lds_bytes(nfc, *g, nang, threads);
   }
   return *lds <= (size_t)c->lds_max;

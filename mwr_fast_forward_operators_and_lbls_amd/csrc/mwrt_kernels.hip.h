@@ -45,7 +45,14 @@ struct LaunchGeom {          // host-computed K2 work split (see plan_k2 in mwrt
   int seglen[2];             // layers per segment
   int npart;                 // doubles of segment partials (B, T) the largest pass needs
   int ldrow;                 // padded LDS row length (doubles) of tau/boft: conflict-free for b64
+  unsigned magic_nseg[2];    // ceil(2^32 / nseg), ceil(2^32 / nang): n / d = umulhi(n, magic) for n < 65536, 1 < d <= 1024
+  unsigned magic_nang;       // (the work-item index splits cost two integer divisions per item otherwise)
 };
+
+// n / d for the small operands of the K2 work split (see LaunchGeom): one v_mul_hi_u32
+__device__ __forceinline__ int div_small(int n, int d, unsigned magic) {
+  return d == 1 ? n : (int)__umulhi((unsigned)n, magic);
+}
 
 // ---------------------------------------------------------------------------------------------
 // small helpers
@@ -1387,8 +1394,8 @@ k_tb_fused(const FusedArgs A) {
     if (sorted) {
       const bool mine = tid < items;
       const int it = mine ? tid : 0;
-      const int pr = it / nseg, seg = it - pr * nseg;
-      const int jj = pr / nang, a = pr - jj * nang;
+      const int pr = div_small(it, nseg, A.g.magic_nseg[h]), seg = it - pr * nseg;
+      const int jj = div_small(pr, nang, A.g.magic_nang), a = pr - jj * nang;
       const int lo = 1 + seg * seglen, hi = min(lo + seglen, nlev);
       float gm = 0.0f;
       for (int g = lo / GRP; g <= (hi - 1) / GRP; ++g) gm = fmaxf(gm, gmax[jj * ngrp + g]);
@@ -1410,8 +1417,8 @@ k_tb_fused(const FusedArgs A) {
         const int key = perm[it0];
         seg = key & 127; jj = (key >> 7) & 15; a = key >> 11;
       } else {
-        const int pr = it0 / nseg;
-        seg = it0 - pr * nseg; jj = pr / nang; a = pr - jj * nang;
+        const int pr = div_small(it0, nseg, A.g.magic_nseg[h]);
+        seg = it0 - pr * nseg; jj = div_small(pr, nang, A.g.magic_nang); a = pr - jj * nang;
       }
       const int it = (jj * nang + a) * nseg + seg;
       const double am = cam[a];
@@ -1478,7 +1485,7 @@ k_tb_fused(const FusedArgs A) {
     }
     __syncthreads();
     for (int pr = tid; pr < npairs; pr += nthreads) {
-      const int jj = pr / nang;
+      const int jj = div_small(pr, nang, A.g.magic_nang);
       const int a = pr - jj * nang;
       const int j = h * NFK + jj;
       double B = 0.0, T = 1.0;
