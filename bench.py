@@ -41,6 +41,10 @@ def parse():
     ap.add_argument("--nprof", type=int, default=1000, help="profiles per GPU")
     ap.add_argument("--model", default="R24")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--per-launch-events", action="store_true",
+                    help="bracket every launch with its own HIP event pair (the library's timing ring) instead of one pair "
+                         "around the K launches: the pure kernel duration, at the price of ~8 us of event packets per step "
+                         "inside the timed region")
     ap.add_argument("--spinup", type=int, default=400,
                     help="untimed launches after the warm-up steps that bring the GPU from its idle power state to its "
                          "sustained clock (a 20-step timed region is 3 ms, shorter than the ramp: the same kernel takes "
@@ -223,7 +227,7 @@ def main():
         works.clear()
         torch.cuda.current_stream().wait_stream(cstream)
 
-    def run_steps(n):
+    def run_steps(n, mark_last=None):
         pending = 0                                    # first slot of the bucket being filled
         for s in range(n):
             slot = s % slots
@@ -231,6 +235,8 @@ def main():
                 drain()
                 pending = 0
             step(s)
+            if mark_last is not None and s == n - 1:
+                mark_last.record(tstream)              # end of the last launch, before its gather
             # ... and the bucket is cut one step before the end, so that the only gather left exposed after the last
             # launch carries a single batch
             if use_dist and (slot + 1 - pending == bucket or slot == slots - 1 or s >= n - 2):
@@ -239,9 +245,14 @@ def main():
         if use_dist:
             drain()
 
+    token = torch.zeros(1, device=dev) if use_dist else None
+
     def barrier():
+        # a one-element all_reduce on the timing stream: no rank's stream gets past it before every rank's has
+        # reached it (what torch's NCCL barrier does, without its host-side synchronisation: the
+        # torch.cuda.synchronize() the contract asks for follows every call)
         if use_dist:
-            dist.barrier()
+            dist.all_reduce(token)
 
     torch.cuda.synchronize()
     with torch.cuda.stream(tstream):
@@ -251,15 +262,27 @@ def main():
                 run_steps(args.spinup)                      # clock spin-up: untimed, same launches as the timed steps
             barrier()
         torch.cuda.synchronize()
-        ctx.set_timing(True)
+        # Kernel time, live, with HIP events on the stream the kernel is launched on: ONE pair around the K
+        # launches (average launch-to-launch period: an upper bound of the kernel's duration that includes the
+        # inter-launch gap).  A pair around every launch measures the kernel alone but puts two event packets between
+        # consecutive kernels -- 8 us per step of the timed region; --per-launch-events selects that.
+        ctx.set_timing(args.per_launch_events)
+        ev_first = torch.cuda.Event(enable_timing=True)
+        ev_last = torch.cuda.Event(enable_timing=True)
         barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        run_steps(K)
-        torch.cuda.synchronize()
-        barrier()
+        ev_first.record(tstream)
+        run_steps(K, mark_last=ev_last)
+        barrier()                                       # enqueued behind the last launch and the last gather ...
+        torch.cuda.synchronize()                        # ... and waited for here
         t1 = time.perf_counter()
-    kernel_ms_total, launches = ctx.timing_collect()
+    if args.per_launch_events:
+        kernel_ms_total, launches = ctx.timing_collect()
+        kernel_how = "HIP event pair around every launch (library timing ring)"
+    else:
+        kernel_ms_total, launches = ev_first.elapsed_time(ev_last), K
+        kernel_how = "one HIP event pair around the K launches on the launch stream / K (includes the inter-launch gap)"
     ctx.set_timing(False)
 
     elapsed = torch.tensor([t1 - t0], dtype=torch.float64, device=dev)
@@ -299,6 +322,7 @@ def main():
                          "unit": "TFLOP/s", "frac": tflops / roofline.FP64_VALU_PEAK_TFLOPS,
                          "traffic": traffic, "traffic_source": traffic_src,
                          "kernel": "k_tb_fused", "kernel_ms": kernel_ms, "launches_timed": launches,
+                         "kernel_ms_method": kernel_how,
                          "algorithmic_flops_per_launch": aflops,
                          "hbm": {"bound": "hbm", "achieved": gbs, "peak": roofline.HBM_PEAK_GBS, "unit": "GB/s",
                                  "frac": gbs / roofline.HBM_PEAK_GBS, "traffic": traffic,
