@@ -189,23 +189,20 @@ __device__ __forceinline__ float row16_max(float m) {
 constexpr int K2_SORT_MIN_SEGLEN = 16;     // shorter segments: dealing the items out costs more than the thin step saves
 
 // Planck function in pyrtlib's units, B = 1 / (exp(x) - 1), x = h f / (k T).  In the microwave x is a few
-// 1e-3: when the whole wave has x <= 1/32 the series (e^x - 1)/x = sum x^n/(n+1)! (8 terms, truncation
-// 2e-17) replaces exp-and-subtract -- 12 VALU instead of 27, and without the cancellation of exp(x) - 1
-// (which costs pyrtlib itself ~3e-14 relative; the difference is far below the parity bar).
+// 1e-3: when the whole wave has x <= 1/32, B = (1/x) * x/(e^x - 1) with the Bernoulli series
+// x/(e^x - 1) = 1 - x/2 + x^2/12 - x^4/720 + x^6/30240 (next term 8e-19) and 1/x = (k T / h) * (1/f) from
+// per-level and per-frequency factors the caller holds: 8 VALU, no exp, no reciprocal, and none of the
+// cancellation of exp(x) - 1 (which costs pyrtlib itself ~3e-14 relative; far below the parity bar).
 constexpr double PLANCK_SMALL_X = 0.03125;
-__device__ __forceinline__ double planck_b(double x) {
+__device__ __forceinline__ double planck_b(double x, double inv_x) {
   if (__all(x <= PLANCK_SMALL_X && x > 0.0)) {
-    double q = 2.4801587301587302e-05;                 // 1/8!
-    MWRT_FMA_SC(q, x, 1.9841269841269841e-04);         // 1/7!
-    MWRT_FMA_SC(q, x, 1.3888888888888889e-03);         // 1/6!
-    MWRT_FMA_SC(q, x, 8.3333333333333332e-03);         // 1/5!
-    MWRT_FMA_SC(q, x, 4.1666666666666664e-02);         // 1/4!
-    MWRT_FMA_SC(q, x, 1.6666666666666666e-01);         // 1/3!
-    q = __builtin_fma(q, x, 0.5);
-    q = __builtin_fma(q, x, 1.0);
-    const double em1 = q * x;
-    double r = __builtin_amdgcn_rcp(em1);
-    return __builtin_fma(r, __builtin_fma(-em1, r, 1.0), r);
+    const double u = x * x;
+    double g = 3.3068783068783071e-05;                 // 1/30240
+    MWRT_FMA_SC(g, u, -1.3888888888888889e-03);        // -1/720
+    MWRT_FMA_SC(g, u, 8.3333333333333329e-02);         // 1/12
+    g = __builtin_fma(g, u, 1.0);
+    g = __builtin_fma(x, -0.5, g);
+    return g * inv_x;
   }
   return fdiv(1.0, fexp(x) - 1.0);
 }
@@ -1138,7 +1135,7 @@ k_tb_fused(const FusedArgs A) {
   int* wcnt = (int*)(gmax + (size_t)NFK * ngrp);          // [nwaves] thin work items per wave
   int* perm = wcnt + nwaves;                              // [nthreads] work items, thin ones first
   __shared__ int s_flag;
-  __shared__ double sfq[3 * NFC + 2];                     // {f, f^2} per slot, {fmin, fmax}, N2 fdep per slot (broadcast reads)
+  __shared__ double sfq[4 * NFC + 2];                     // {f, f^2} per slot, {fmin, fmax}, N2 fdep per slot, 1/f per slot (broadcast reads)
 
   // uniform frequency chunk; slots beyond nfc reuse the last valid one (results discarded)
   if (tid == 0) s_flag = 0;
@@ -1148,6 +1145,7 @@ k_tb_fused(const FusedArgs A) {
     double fdep = 1.0;
     if (M->n2_fdep) { const double q = f * (1.0 / 450.0); fdep = 0.5 + fdiv(0.5, 1.0 + q * q); }
     sfq[2 * NFC + 2 + tid] = fdep;
+    sfq[3 * NFC + 2 + tid] = fdiv(1.0, f);
   }
   if (tid == WAVE - 1) {
     double lo = cfrq[jbase], hi = lo;
@@ -1283,6 +1281,7 @@ k_tb_fused(const FusedArgs A) {
     return;
   }
   const double hk = 1e9 * M->planck_h / M->boltzmann_k;
+  const double inv_hk = 1e-9 * M->boltzmann_k / M->planck_h;
   // The TB-only instantiation (EXTRAS = false) carries none of the by-product code: the compiler would
   // otherwise evaluate tbatm / tmr speculatively and keep the opacity sums' registers alive.
   bool want_tau = false;
@@ -1312,6 +1311,7 @@ k_tb_fused(const FusedArgs A) {
     const bool sorted = !(OPT && A.amf) && items <= nthreads && seglen >= K2_SORT_MIN_SEGLEN;
     if (wave_live) {
       const double hkt = fdiv(hk, ti);                  // h / (k T) per GHz
+      const double kth = ti * inv_hk;                   // its inverse, without a second division per lane
 #pragma unroll
       for (int jj = 0; jj < NFK; ++jj) {
         const int j = h * NFK + jj;
@@ -1319,7 +1319,7 @@ k_tb_fused(const FusedArgs A) {
           double tz = td[j];
           if constexpr (EXTRAS) tz = tw[j] + td[j];
           if constexpr (CLOUD_ROWS) tz = (tz + tci[j]) + tl[j];
-          const double bz = planck_b(sfq[2 * j] * hkt);
+          const double bz = planck_b(sfq[2 * j] * hkt, sfq[3 * NFC + 2 + j] * kth);
           if (active) { tau[jj * ld + tid] = tz; bof[jj * ld + tid] = bz; }
           // largest layer value of each group of 16 levels (rounded up): decides once per work item whether
           // every layer of its segment is thin at its airmass
