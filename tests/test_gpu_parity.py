@@ -596,6 +596,35 @@ def test_wrapper_cli_script(gpu_ctx, tmp_path):
         assert "TBs_PyRTlib_" + tag in back
 
 
+def test_wrapper_cli_netcdf4_in_and_out(gpu_ctx, tmp_path):
+    """The same script on the reference's own file format without xarray: NetCDF-4 (HDF5) in -- the h5py-written
+    fixture of tests/golden/ -- and, with --netcdf4, NETCDF4_CLASSIC out (PyRTlib_processing.py:205, :211), both
+    through libhdf5 (netcdf4_io)."""
+    import subprocess
+    import sys
+    from mwr_fast_forward_operators_and_lbls_amd import netcdf4_io as nio
+    if not nio.available():
+        pytest.skip("no HDF5 shared library on this machine")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    inp = os.path.join(root, "tests", "golden", "netcdf4_h5py_fixture.nc")
+    out = str(tmp_path / "out_nc4.nc")
+    r = subprocess.run([sys.executable, "-m", "mwr_fast_forward_operators_and_lbls_amd.pyrtlib_processing",
+                        "-i", inp, "--output", out, "--netcdf4"], cwd=root, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert nio.is_hdf5(out)
+    src, back = nio.read_netcdf4(inp), nio.read_netcdf4(out)
+    tb = back["TBs_PyRTlib_R24"]
+    assert tb.dims == ("time", "N_Channels", "elevation", "Crop") and tb.values.shape == (3, 14, 3, 2)
+    assert np.isnan(tb.values[1, :, :, 1]).all() and np.isfinite(tb.values[0]).all()      # the profile with the masked RH
+    # profile (time 2, Crop 0) against the oracle, inputs converted as the wrapper does (top -> ground, m, %)
+    z = src["Level_z"].values[::-1, 2, 0] / 1000.0
+    p, t = src["Level_Pressure"].values[::-1, 2, 0], src["Level_Temperature"].values[::-1, 2, 0].astype(np.float64)
+    rh = src["Level_RH"].values[::-1, 2, 0] / 100.0
+    ref = lo.tb_cloud_rte(sp.get_model("R24"), z, p, t, rh, pr.HATPRO_FRQS, src["elevation"].values)["tbtotal"].reshape(3, 14)
+    assert np.abs(tb.values[2, :, :, 0].T - ref).max() <= TOL_K
+    assert np.array_equal(back["Level_Pressure"].values, src["Level_Pressure"].values)
+
+
 def test_hip_graph_capture_of_the_four_model_sequence(gpu_ctx):
     """The device entry point is capture-safe once frequencies/angles are cached: the wrapper's four
     model runs (PyRTlib_processing.py:121-151) captured into ONE hipGraph and replayed."""
