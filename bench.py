@@ -45,7 +45,7 @@ def parse():
                     help="bracket every launch with its own HIP event pair (the library's timing ring) instead of one pair "
                          "around the K launches: the pure kernel duration, at the price of ~8 us of event packets per step "
                          "inside the timed region")
-    ap.add_argument("--spinup", type=int, default=400,
+    ap.add_argument("--spinup", type=int, default=800,
                     help="untimed launches after the warm-up steps that bring the GPU from its idle power state to its "
                          "sustained clock (a 20-step timed region is 3 ms, shorter than the ramp: the same kernel takes "
                          "150 us right after idle and 133 us sustained); 0 = none")
