@@ -1135,7 +1135,7 @@ k_tb_fused(const FusedArgs A) {
   int* wcnt = (int*)(gmax + (size_t)NFK * ngrp);          // [nwaves] thin work items per wave
   int* perm = wcnt + nwaves;                              // [nthreads] work items, thin ones first
   __shared__ int s_flag;
-  __shared__ double sfq[4 * NFC + 2];                     // {f, f^2} per slot, {fmin, fmax}, N2 fdep per slot, 1/f per slot (broadcast reads)
+  __shared__ double sfq[5 * NFC + 2];                     // {f, f^2} per slot, {fmin, fmax}, N2 fdep, 1/f, cosmic-background Planck term per slot
 
   // uniform frequency chunk; slots beyond nfc reuse the last valid one (results discarded)
   if (tid == 0) s_flag = 0;
@@ -1146,6 +1146,8 @@ k_tb_fused(const FusedArgs A) {
     if (M->n2_fdep) { const double q = f * (1.0 / 450.0); fdep = 0.5 + fdiv(0.5, 1.0 + q * q); }
     sfq[2 * NFC + 2 + tid] = fdep;
     sfq[3 * NFC + 2 + tid] = fdiv(1.0, f);
+    // B(T_cosmic, f): one value per frequency, not per (frequency, angle) pair
+    sfq[4 * NFC + 2 + tid] = fdiv(1.0, fexp(fdiv(f * (1e9 * M->planck_h / M->boltzmann_k), M->t_cosmic)) - 1.0);
   }
   if (tid == WAVE - 1) {
     double lo = cfrq[jbase], hi = lo;
@@ -1500,7 +1502,7 @@ k_tb_fused(const FusedArgs A) {
       // cosmic term is 1e-54 of B either way)
       if (T > TRANS_MIN) {
         const double ex = T;
-        const double bbg = fdiv(1.0, fexp(fdiv(hvk, M->t_cosmic)) - 1.0);
+        const double bbg = sfq[4 * NFC + 2 + j];
         boftotl = __builtin_fma(bbg, ex, B);
         boftmr = EXTRAS ? fdiv(B, 1.0 - ex) : 0.0;
       } else {
