@@ -8,9 +8,13 @@ OUT=gpurun_out/$TAG
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 mkdir -p $OUT
 # 1. the bench line itself, then the same command under the kernel trace
-python3 bench.py --steps 50 --warmup 10 > $OUT/bench_cfg3.json 2> $OUT/bench_cfg3.err
-python3 bench.py --config 2 --steps 50 --warmup 10 --no-cpu-baseline > $OUT/bench_cfg2.json 2> $OUT/bench_cfg2.err
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_cfg3 -- python3 bench.py --steps 50 --warmup 10 --no-cpu-baseline > $OUT/trace_cfg3.json 2> $OUT/trace_cfg3.err
+# (the driver's flags; bench.py adds its clock spin-up by default: --spinup 0 = right after idle)
+python3 bench.py --steps 20 --warmup 5 > $OUT/bench_cfg3.json 2> $OUT/bench_cfg3.err
+python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --per-launch-events > $OUT/bench_cfg3_per_launch_events.json 2>> $OUT/bench_cfg3.err
+python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --spinup 0 > $OUT/bench_cfg3_cold_start.json 2>> $OUT/bench_cfg3.err
+python3 bench.py --config 2 --steps 20 --warmup 5 --no-cpu-baseline > $OUT/bench_cfg2.json 2> $OUT/bench_cfg2.err
+python3 bench.py --config 2 --steps 20 --warmup 5 --no-cpu-baseline --spinup 0 > $OUT/bench_cfg2_cold_start.json 2>> $OUT/bench_cfg2.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_cfg3 -- python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline > $OUT/trace_cfg3.json 2> $OUT/trace_cfg3.err
 cp $(ls $OUT/trace_cfg3/*/*kernel_stats.csv | head -1) $OUT/bench_cfg3_kernel_stats.csv
 # 2. PMC passes
 bash tools/pmc_passes.sh $OUT/pmc_cfg3 3 > /dev/null
