@@ -1,0 +1,66 @@
+"""Randomised HIP-vs-oracle parity hunt (GPU box; the C oracle is the checker, as in tests/).
+
+Random level counts (20..400), elevation sets (1..12 angles, 2..90 degrees, sometimes one NaN), frequency sets
+(1..40 frequencies, the HATPRO list, clustered near line centres, or uniform 10..200 GHz), models, and profile
+perturbations (dry / saturated columns, cold stratospheres), for a wall-clock budget.  Prints the worst deviation and
+fails (exit 1) on anything above 1e-6 K or a validity-flag mismatch.
+
+    python tools/fuzz_parity.py [seconds] [seed]
+"""
+import sys, os, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import warnings
+import numpy as np
+warnings.simplefilter("ignore")
+from mwr_fast_forward_operators_and_lbls_amd import _native, profiles as pr, spectroscopy as sp
+from oracle import c_oracle as co
+
+budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
+seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+rng = np.random.default_rng(seed)
+ctx = _native.Context(0)
+models = ["R98", "R17", "R20", "R20SD", "R24"]
+centres = np.array([22.235, 50.474, 53.067, 56.264, 58.447, 60.306, 62.486, 118.750, 183.310])
+worst, cases, evals = 0.0, 0, 0
+t_end = time.time() + budget
+while time.time() < t_end:
+    nlev = int(rng.choice([20, 33, 64, 65, 100, 180, 180, 180, 257, 400]))
+    nprof = int(rng.integers(1, 6))
+    P = pr.synthetic_profiles(nprof, int(rng.integers(0, 10**6)), nlev=nlev)
+    kind = rng.integers(0, 5)
+    if kind == 1: P["rh"] *= 0.01
+    if kind == 2: P["rh"] = np.minimum(1.0, P["rh"] * 4.0)
+    if kind == 3: P["t"][:, nlev // 2:] -= rng.uniform(0, 25)
+    nang = int(rng.integers(1, 13))
+    ang = np.sort(rng.uniform(2.0, 90.0, nang))[::-1].copy()
+    if rng.random() < 0.3: ang[0] = 90.0
+    nan_k = int(rng.integers(0, nang)) if (nang > 1 and rng.random() < 0.15) else -1
+    fk = rng.integers(0, 4)
+    if fk == 0: frq = pr.HATPRO_FRQS
+    elif fk == 1: frq = np.sort(rng.uniform(10.0, 200.0, int(rng.integers(1, 41))))
+    elif fk == 2: frq = np.sort(np.concatenate([c + rng.normal(0, 0.3, 3) for c in rng.choice(centres, 4)]))
+    else: frq = np.linspace(*sorted(rng.uniform(15.0, 70.0, 2)), int(rng.integers(2, 35)))
+    frq = np.ascontiguousarray(np.maximum(frq, 1.0))
+    name = str(rng.choice(models))
+    m = sp.get_model(name)
+    a_in = ang.copy()
+    if nan_k >= 0: a_in[nan_k] = np.nan
+    tb, valid = ctx.tb_batch(name, P["z"], P["p"], P["t"], P["rh"], frq, a_in)
+    good = ~np.isnan(a_in)
+    for i in range(nprof):
+        try:
+            ref = co.tb_profile(m, P["z"][i], P["p"][i], P["t"][i], P["rh"][i], frq, ang[good])["tbtotal"].reshape(good.sum(), len(frq))
+            ok = 1
+        except ValueError:
+            ok = 2
+        if valid[i] != ok:
+            print("FLAG MISMATCH", dict(nlev=nlev, nang=nang, nf=len(frq), model=name, kind=int(kind), i=i, hip=int(valid[i]), oracle=ok)); sys.exit(1)
+        if ok == 1:
+            dev = float(np.abs(tb[i][good] - ref).max())
+            if nan_k >= 0 and not np.isnan(tb[i][nan_k]).all():
+                print("NaN ROW NOT NaN", nlev, nang, len(frq)); sys.exit(1)
+            if not (dev <= 1e-6):
+                print("DEVIATION", dev, dict(nlev=nlev, nang=nang, nf=len(frq), model=name, kind=int(kind), i=i, frq=frq.tolist(), ang=ang.tolist())); sys.exit(1)
+            worst = max(worst, dev); evals += ref.size
+    cases += 1
+print(f"fuzz ok: {cases} calls, {evals} TB evaluations checked against oracle/lbl_oracle.c, worst |dTB| = {worst:.3e} K (seed {seed}, {budget:.0f} s)")
