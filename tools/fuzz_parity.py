@@ -5,7 +5,7 @@ Random level counts (20..400), elevation sets (1..12 angles, 2..90 degrees, some
 perturbations (dry / saturated columns, cold stratospheres), for a wall-clock budget.  Prints the worst deviation and
 fails (exit 1) on anything above 1e-6 K or a validity-flag mismatch.
 
-    python tools/fuzz_parity.py [seconds] [seed]
+    python tools/fuzz_parity.py [seconds] [seed] [opt]      (opt: also cloud liquid / ice and ray tracing, randomly)
 """
 import sys, os, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -17,6 +17,7 @@ from oracle import c_oracle as co
 
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
 seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+with_opt = len(sys.argv) > 3 and sys.argv[3] == "opt"
 rng = np.random.default_rng(seed)
 ctx = _native.Context(0)
 models = ["R98", "R17", "R20", "R20SD", "R24"]
@@ -45,22 +46,44 @@ while time.time() < t_end:
     m = sp.get_model(name)
     a_in = ang.copy()
     if nan_k >= 0: a_in[nan_k] = np.nan
-    tb, valid = ctx.tb_batch(name, P["z"], P["p"], P["t"], P["rh"], frq, a_in)
+    lwc = iwc = None
+    rays = False
+    if with_opt:
+        if rng.random() < 0.7:
+            lwc, iwc = np.zeros((nprof, nlev)), np.zeros((nprof, nlev))
+            for i in range(nprof):
+                if rng.random() < 0.8:
+                    b = int(rng.integers(1, max(2, nlev // 3))); w = int(rng.integers(1, max(2, nlev // 10)))
+                    lwc[i, b:b + w] = rng.uniform(0.01, 0.6, len(lwc[i, b:b + w]))
+                if rng.random() < 0.5:
+                    b = int(rng.integers(nlev // 2, nlev - 2)); w = int(rng.integers(1, max(2, nlev // 12)))
+                    iwc[i, b:b + w] = rng.uniform(0.005, 0.1, len(iwc[i, b:b + w]))
+        rays = bool(rng.random() < 0.6)
+    if with_opt:
+        tb, valid = ctx.tb_batch(name, P["z"], P["p"], P["t"], P["rh"], frq, a_in, denliq=lwc, denice=iwc, ray_tracing=rays)
+    else:
+        tb, valid = ctx.tb_batch(name, P["z"], P["p"], P["t"], P["rh"], frq, a_in)
     good = ~np.isnan(a_in)
     for i in range(nprof):
         try:
-            ref = co.tb_profile(m, P["z"][i], P["p"][i], P["t"][i], P["rh"][i], frq, ang[good])["tbtotal"].reshape(good.sum(), len(frq))
+            if with_opt:
+                ref = co.tb_profile_opt(m, P["z"][i], P["p"][i], P["t"][i], P["rh"][i], frq, ang[good],
+                                        None if lwc is None else lwc[i], None if iwc is None else iwc[i], rays)["tbtotal"].reshape(good.sum(), len(frq))
+            else:
+                ref = co.tb_profile(m, P["z"][i], P["p"][i], P["t"][i], P["rh"][i], frq, ang[good])["tbtotal"].reshape(good.sum(), len(frq))
             ok = 1
-        except ValueError:
-            ok = 2
+        except ValueError as err:
+            ok = 3 if "RayTrac" in str(err) else 2
         if valid[i] != ok:
             print("FLAG MISMATCH", dict(nlev=nlev, nang=nang, nf=len(frq), model=name, kind=int(kind), i=i, hip=int(valid[i]), oracle=ok)); sys.exit(1)
         if ok == 1:
-            dev = float(np.abs(tb[i][good] - ref).max())
+            both_nan = np.isnan(tb[i][good]) & np.isnan(ref)           # a trapped ray of one angle: NaN on both sides
+            dev = float(np.abs(np.where(both_nan, 0.0, tb[i][good] - ref)).max())
             if nan_k >= 0 and not np.isnan(tb[i][nan_k]).all():
                 print("NaN ROW NOT NaN", nlev, nang, len(frq)); sys.exit(1)
             if not (dev <= 1e-6):
                 print("DEVIATION", dev, dict(nlev=nlev, nang=nang, nf=len(frq), model=name, kind=int(kind), i=i, frq=frq.tolist(), ang=ang.tolist())); sys.exit(1)
             worst = max(worst, dev); evals += ref.size
     cases += 1
-print(f"fuzz ok: {cases} calls, {evals} TB evaluations checked against oracle/lbl_oracle.c, worst |dTB| = {worst:.3e} K (seed {seed}, {budget:.0f} s)")
+tag = ", with cloud / ray tracing" if with_opt else ""
+print(f"fuzz ok: {cases} calls, {evals} TB evaluations checked against oracle/lbl_oracle.c, worst |dTB| = {worst:.3e} K (seed {seed}, {budget:.0f} s{tag})")
