@@ -18,6 +18,7 @@ from oracle import c_oracle as co
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
 seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 with_opt = len(sys.argv) > 3 and sys.argv[3] == "opt"
+fine = len(sys.argv) > 3 and sys.argv[3] == "fine"      # fine grids: the windowed K1 -> alpha -> K2 path
 rng = np.random.default_rng(seed)
 ctx = _native.Context(0)
 models = ["R98", "R17", "R20", "R20SD", "R24"]
@@ -41,6 +42,14 @@ while time.time() < t_end:
     elif fk == 1: frq = np.sort(rng.uniform(10.0, 200.0, int(rng.integers(1, 41))))
     elif fk == 2: frq = np.sort(np.concatenate([c + rng.normal(0, 0.3, 3) for c in rng.choice(centres, 4)]))
     else: frq = np.linspace(*sorted(rng.uniform(15.0, 70.0, 2)), int(rng.integers(2, 35)))
+    if fine:
+        nf = int(rng.integers(128, 420))
+        lo_f = float(rng.uniform(15.0, 190.0))
+        frq = lo_f + np.cumsum(rng.uniform(0.2, 1.0, nf)) * (float(rng.uniform(1.0, 5.5)) / 128.0) / 0.6
+        nprof, nang = 1, min(nang, 3)
+        P = {k: v[:1] for k, v in P.items()}
+        ang = ang[:nang].copy()
+        nan_k = -1
     frq = np.ascontiguousarray(np.maximum(frq, 1.0))
     name = str(rng.choice(models))
     m = sp.get_model(name)
@@ -85,5 +94,5 @@ while time.time() < t_end:
                 print("DEVIATION", dev, dict(nlev=nlev, nang=nang, nf=len(frq), model=name, kind=int(kind), i=i, frq=frq.tolist(), ang=ang.tolist())); sys.exit(1)
             worst = max(worst, dev); evals += ref.size
     cases += 1
-tag = ", with cloud / ray tracing" if with_opt else ""
+tag = ", with cloud / ray tracing" if with_opt else (", fine grids (windowed path)" if fine else "")
 print(f"fuzz ok: {cases} calls, {evals} TB evaluations checked against oracle/lbl_oracle.c, worst |dTB| = {worst:.3e} K (seed {seed}, {budget:.0f} s{tag})")
