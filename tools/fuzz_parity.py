@@ -18,6 +18,7 @@ from oracle import c_oracle as co
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
 seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 with_opt = len(sys.argv) > 3 and sys.argv[3] == "opt"
+extras = len(sys.argv) > 3 and sys.argv[3] == "extras"    # every DataFrame column of execute()
 fine = len(sys.argv) > 3 and sys.argv[3] == "fine"      # fine grids: the windowed K1 -> alpha -> K2 path
 rng = np.random.default_rng(seed)
 ctx = _native.Context(0)
@@ -70,6 +71,8 @@ while time.time() < t_end:
         rays = bool(rng.random() < 0.6)
     if with_opt:
         tb, valid = ctx.tb_batch(name, P["z"], P["p"], P["t"], P["rh"], frq, a_in, denliq=lwc, denice=iwc, ray_tracing=rays)
+    elif extras:
+        tb, valid, ex = ctx.tb_batch(name, P["z"], P["p"], P["t"], P["rh"], frq, a_in, extras=True)
     else:
         tb, valid = ctx.tb_batch(name, P["z"], P["p"], P["t"], P["rh"], frq, a_in)
     good = ~np.isnan(a_in)
@@ -79,7 +82,14 @@ while time.time() < t_end:
                 ref = co.tb_profile_opt(m, P["z"][i], P["p"][i], P["t"][i], P["rh"][i], frq, ang[good],
                                         None if lwc is None else lwc[i], None if iwc is None else iwc[i], rays)["tbtotal"].reshape(good.sum(), len(frq))
             else:
-                ref = co.tb_profile(m, P["z"][i], P["p"][i], P["t"][i], P["rh"][i], frq, ang[good])["tbtotal"].reshape(good.sum(), len(frq))
+                full = co.tb_profile(m, P["z"][i], P["p"][i], P["t"][i], P["rh"][i], frq, ang[good])
+                ref = full["tbtotal"].reshape(good.sum(), len(frq))
+                if extras:
+                    for k, tol in (("tbatm", 1e-6), ("tauwet", None), ("taudry", None), ("tmr", 1e-5)):
+                        got, want = ex[k][i][good], full[k].reshape(good.sum(), len(frq))
+                        bad = (np.abs(got - want) > tol) if tol else (np.abs(got - want) > 1e-9 * np.abs(want) + 1e-14)
+                        if bad.any():
+                            print("EXTRAS MISMATCH", k, float(np.abs(got - want).max()), dict(nlev=nlev, nang=nang, nf=len(frq), model=name)); sys.exit(1)
             ok = 1
         except ValueError as err:
             ok = 3 if "RayTrac" in str(err) else 2
@@ -94,5 +104,5 @@ while time.time() < t_end:
                 print("DEVIATION", dev, dict(nlev=nlev, nang=nang, nf=len(frq), model=name, kind=int(kind), i=i, frq=frq.tolist(), ang=ang.tolist())); sys.exit(1)
             worst = max(worst, dev); evals += ref.size
     cases += 1
-tag = ", with cloud / ray tracing" if with_opt else (", fine grids (windowed path)" if fine else "")
+tag = ", with cloud / ray tracing" if with_opt else (", fine grids (windowed path)" if fine else (", all columns" if extras else ""))
 print(f"fuzz ok: {cases} calls, {evals} TB evaluations checked against oracle/lbl_oracle.c, worst |dTB| = {worst:.3e} K (seed {seed}, {budget:.0f} s{tag})")
