@@ -1126,3 +1126,18 @@ def test_layer_step_forms_agree(gpu_ctx, nlev, ang):
     for i in (0, 2, 3):
         ref = lo.tb_cloud_rte(m, P["z"][i], P["p"][i], P["t"][i], P["rh"][i], frq, ang)["tbtotal"]
         assert np.abs(tb[i].ravel() - ref).max() <= 2e-9, i
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["", "opt", "fine", "extras"])
+def test_randomised_parity_hunt_short(gpu_ctx, mode):
+    """Ten seconds of tools/fuzz_parity.py per mode (random level counts, elevation and frequency sets, models,
+    extreme columns; cloud / ray tracing; fine grids; every output column) against the C oracle.  The long runs are
+    in profiles/r02_fuzz_parity.txt."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, os.path.join(root, "tools", "fuzz_parity.py"), "10", "5"] + ([mode] if mode else [])
+    r = subprocess.run(cmd, cwd=root, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-1500:])
+    assert "fuzz ok" in r.stdout
