@@ -19,6 +19,7 @@ budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
 seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 with_opt = len(sys.argv) > 3 and sys.argv[3] == "opt"
 extras = len(sys.argv) > 3 and sys.argv[3] == "extras"    # every DataFrame column of execute()
+wide = len(sys.argv) > 3 and sys.argv[3] == "wide"        # up to 64 elevations: several rounds of K2 work items
 fine = len(sys.argv) > 3 and sys.argv[3] == "fine"      # fine grids: the windowed K1 -> alpha -> K2 path
 rng = np.random.default_rng(seed)
 ctx = _native.Context(0)
@@ -34,7 +35,7 @@ while time.time() < t_end:
     if kind == 1: P["rh"] *= 0.01
     if kind == 2: P["rh"] = np.minimum(1.0, P["rh"] * 4.0)
     if kind == 3: P["t"][:, nlev // 2:] -= rng.uniform(0, 25)
-    nang = int(rng.integers(1, 13))
+    nang = int(rng.integers(1, 65 if wide else 13))
     ang = np.sort(rng.uniform(2.0, 90.0, nang))[::-1].copy()
     if rng.random() < 0.3: ang[0] = 90.0
     nan_k = int(rng.integers(0, nang)) if (nang > 1 and rng.random() < 0.15) else -1
@@ -104,5 +105,5 @@ while time.time() < t_end:
                 print("DEVIATION", dev, dict(nlev=nlev, nang=nang, nf=len(frq), model=name, kind=int(kind), i=i, frq=frq.tolist(), ang=ang.tolist())); sys.exit(1)
             worst = max(worst, dev); evals += ref.size
     cases += 1
-tag = ", with cloud / ray tracing" if with_opt else (", fine grids (windowed path)" if fine else (", all columns" if extras else ""))
+tag = ", with cloud / ray tracing" if with_opt else (", fine grids (windowed path)" if fine else (", all columns" if extras else (", up to 64 elevations" if wide else "")))
 print(f"fuzz ok: {cases} calls, {evals} TB evaluations checked against oracle/lbl_oracle.c, worst |dTB| = {worst:.3e} K (seed {seed}, {budget:.0f} s{tag})")
