@@ -52,6 +52,31 @@ def parse():
     return ap.parse_args()
 
 
+def usable_cores():
+    """Host cores this process may actually use: the scheduler affinity mask, capped by the cgroup CPU quota (a GPU
+    box hands each job a share of a large host -- os.cpu_count() reports the whole machine)."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    quota = None
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as fh:                  # cgroup v2: "<quota> <period>" or "max <period>"
+            q, per = fh.read().split()
+            if q != "max":
+                quota = float(q) / float(per)
+    except (OSError, ValueError):
+        try:
+            with open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us") as fq, open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as fp:
+                qv, pv = float(fq.read()), float(fp.read())
+                if qv > 0:
+                    quota = qv / pv
+        except (OSError, ValueError):
+            quota = None
+    used = n if quota is None else max(1, min(n, int(quota + 0.5)))
+    return used, {"os_cpu_count": os.cpu_count(), "sched_affinity": n, "cgroup_cpu_quota": quota}
+
+
 def cpu_baseline(tables, P, frq, ang, budget_s=20.0):
     """oracle/lbl_oracle.c (the 'port') timed on this box's host cores, bounded sample."""
     from oracle import c_oracle
@@ -68,9 +93,9 @@ def cpu_baseline(tables, P, frq, ang, budget_s=20.0):
         tb, _ = c_oracle.tb_batch(tables, P["z"][:n], P["p"][:n], P["t"][:n], P["rh"][:n], frq, ang, nthreads=1)
         dt1 += time.perf_counter() - t0
         passes += 1
-    cores = os.cpu_count() or 1
-    # all host cores (OpenMP over profiles): one untimed pass spins the thread team up, then whole
-    # passes are repeated until >= 5 s have been timed
+    cores, cores_info = usable_cores()
+    # all usable host cores (OpenMP over profiles, schedule(dynamic, 4)): one untimed pass spins the thread team up,
+    # then whole passes are repeated until >= 5 s have been timed
     c_oracle.tb_batch(tables, P["z"], P["p"], P["t"], P["rh"], frq, ang, nthreads=cores)
     passes_n, dtn = 0, 0.0
     while dtn < 5.0 and passes_n < 4096:
@@ -104,7 +129,8 @@ def cpu_baseline(tables, P, frq, ang, budget_s=20.0):
             "sample": f"{passes} pass(es) over {n} of the {P['z'].shape[0]} profiles x {len(frq)} ch x {len(ang)} elev, "
                       f"oracle/lbl_oracle.c (pyrtlib loop order), {dt1:.1f} s on 1 core",
             "all_cores": {"value": passes_n * P["z"].shape[0] * ev / dtn, "cores": cores, "seconds": round(dtn, 2),
-                          "passes": passes_n},
+                          "passes": passes_n, "speedup_over_one_core": (passes_n * P["z"].shape[0] * ev / dtn) / (passes * n * ev / dt1),
+                          "threads_used": cores, **cores_info},
             "pyrtlib_shaped_numpy": {"value": npy * ev / dtp, "cores": 1, "profiles": npy,
                                      "what": "oracle/lbl_oracle.py, pyrtlib's loop structure in NumPy"},
             "genuine_pyrtlib": genuine}, tb, n
@@ -207,43 +233,18 @@ def main():
     batch_bytes = nprof * nang * nf * 8
     bucket = max(1, min(slots, int(round(4e6 / batch_bytes))))
     gathered = torch.empty((world, slots, nprof, nang, nf), dtype=torch.float64, device=dev) if use_dist else None
-    works = []
+    # distributed.GatherRing owns the exchange (bucketed all_gather on the second stream, ring wrap, bucket cut one
+    # step before the end); the same class runs under gloo on CPU tensors in tests/test_distributed_gloo.py
+    from mwr_fast_forward_operators_and_lbls_amd.distributed import GatherRing
+    ring = GatherRing(out, gathered, bucket, compute_stream=tstream, comm_stream=cstream if use_dist else None,
+                      collective=use_dist)
 
     def step(s):
         ctx.tb_batch_device(tables, nprof, nlev, d["z"].data_ptr(), d["p"].data_ptr(), d["t"].data_ptr(),
                             d["rh"].data_ptr(), frq, ang, out[s % slots].data_ptr(), valid.data_ptr(), stream=stream)
 
-    def gather_slots(b0, b1):
-        """all_gather of result slots [b0, b1) on the communication stream, behind the launches that wrote them"""
-        ev = torch.cuda.Event()
-        ev.record(tstream)
-        cstream.wait_event(ev)
-        with torch.cuda.stream(cstream):
-            works.append(dist.all_gather([gathered[r, b0:b1] for r in range(world)], out[b0:b1], async_op=True))
-
-    def drain():
-        for w in works:
-            w.wait()                                   # the current stream waits for the collective
-        works.clear()
-        torch.cuda.current_stream().wait_stream(cstream)
-
     def run_steps(n, mark_last=None):
-        pending = 0                                    # first slot of the bucket being filled
-        for s in range(n):
-            slot = s % slots
-            if slot == 0 and s > 0:                    # ring wrap: the slots about to be overwritten must have left
-                drain()
-                pending = 0
-            step(s)
-            if mark_last is not None and s == n - 1:
-                mark_last.record(tstream)              # end of the last launch, before its gather
-            # ... and the bucket is cut one step before the end, so that the only gather left exposed after the last
-            # launch carries a single batch
-            if use_dist and (slot + 1 - pending == bucket or slot == slots - 1 or s >= n - 2):
-                gather_slots(pending, slot + 1)
-                pending = slot + 1
-        if use_dist:
-            drain()
+        ring.run(step, n, mark_last=mark_last)
 
     token = torch.zeros(1, device=dev) if use_dist else None
 
@@ -254,14 +255,8 @@ def main():
         if use_dist:
             dist.all_reduce(token)
 
-    torch.cuda.synchronize()
-    with torch.cuda.stream(tstream):
-        with _stdout_to_stderr():                       # RCCL's banner at the first collective
-            run_steps(W if W > 0 or not use_dist else 1)    # warm-up (the collective too)
-            if args.spinup > 0:
-                run_steps(args.spinup)                      # clock spin-up: untimed, same launches as the timed steps
-            barrier()
-        torch.cuda.synchronize()
+    def timed_region():
+        """EXACTLY K steps between barrier + synchronize on both sides -> (wall seconds, kernel ms total, launches)"""
         # Kernel time, live, with HIP events on the stream the kernel is launched on: ONE pair around the K
         # launches (average launch-to-launch period: an upper bound of the kernel's duration that includes the
         # inter-launch gap).  A pair around every launch measures the kernel alone but puts two event packets between
@@ -277,18 +272,43 @@ def main():
         barrier()                                       # enqueued behind the last launch and the last gather ...
         torch.cuda.synchronize()                        # ... and waited for here
         t1 = time.perf_counter()
-    if args.per_launch_events:
-        kernel_ms_total, launches = ctx.timing_collect()
-        kernel_how = "HIP event pair around every launch (library timing ring)"
-    else:
-        kernel_ms_total, launches = ev_first.elapsed_time(ev_last), K
-        kernel_how = "one HIP event pair around the K launches on the launch stream / K (includes the inter-launch gap)"
-    ctx.set_timing(False)
+        if args.per_launch_events:
+            kms, launches = ctx.timing_collect()
+        else:
+            kms, launches = ev_first.elapsed_time(ev_last), K
+        ctx.set_timing(False)
+        return t1 - t0, kms, launches
+
+    torch.cuda.synchronize()
+    cold = None
+    with torch.cuda.stream(tstream):
+        with _stdout_to_stderr():                       # RCCL's banner at the first collective
+            run_steps(W if W > 0 or not use_dist else 1)    # warm-up (the collective too)
+            barrier()
+        torch.cuda.synchronize()
+        if args.spinup > 0:
+            # The state the driver's flags alone produce -- K steps right after the W warm-up steps, the GPU still
+            # on its way out of the idle power state -- is timed first and reported as "cold_start" beside the headline.
+            cold = timed_region()
+            with _stdout_to_stderr():
+                run_steps(args.spinup)                      # clock spin-up: untimed, same launches as the timed steps
+                barrier()
+            torch.cuda.synchronize()
+        dt, kernel_ms_total, launches = timed_region()
+    t0, t1 = 0.0, dt
+    kernel_how = ("HIP event pair around every launch (library timing ring)" if args.per_launch_events else
+                  "one HIP event pair around the K launches on the launch stream / K (includes the inter-launch gap)")
 
     elapsed = torch.tensor([t1 - t0], dtype=torch.float64, device=dev)
     if use_dist:
         dist.all_reduce(elapsed, op=dist.ReduceOp.MAX)
     elapsed = float(elapsed.item())
+    cold_elapsed = None
+    if cold is not None:
+        ce = torch.tensor([cold[0]], dtype=torch.float64, device=dev)
+        if use_dist:
+            dist.all_reduce(ce, op=dist.ReduceOp.MAX)
+        cold_elapsed = float(ce.item())
 
     if rank == 0:
         evals_per_step = world * nprof * nf * nang
@@ -328,6 +348,13 @@ def main():
                                  "frac": gbs / roofline.HBM_PEAK_GBS, "traffic": traffic,
                                  "algorithmic_bytes_per_launch": abytes}},
         }
+        if cold is not None:
+            ckms = cold[1] / max(cold[2], 1)
+            res["cold_start"] = {
+                "what": f"the same K = {K} timed steps taken right after the W = {W} warm-up steps, BEFORE the "
+                        f"{args.spinup} untimed spin-up launches (GPU still leaving its idle power state)",
+                "ms_per_step": cold_elapsed / K * 1e3, "value": evals_per_step * K / cold_elapsed,
+                "kernel_ms": ckms, "roofline_frac": aflops / (ckms * 1e-3) / 1e12 / roofline.FP64_VALU_PEAK_TFLOPS}
         # parity spot check (not timed): HIP result of the last step vs the C oracle
         tb_gpu = out[(K - 1) % slots].cpu().numpy()
         if world == 1 and not args.no_cpu_baseline:

@@ -66,7 +66,7 @@
 extern "C" {
 #endif
 
-#define MWRT_VERSION 200          /* 0.2.0: mwrt_tb_options, tauliq / tauice extras, liq_mode, MWRT_STREAM_LEGACY */
+#define MWRT_VERSION 300          /* 0.3.0: layer-optical-depth two-kernel form (mwrt_layer_tau_*, mwrt_tb_from_layer_tau_device) */
 #define MWRT_MAX_H2O_LINES 32
 #define MWRT_MAX_O2_LINES 64
 #define MWRT_MAX_LEVELS 1024      /* one lane per level, one workgroup per profile */
@@ -221,11 +221,15 @@ int mwrt_absorption_batch_device(mwrt_context* ctx, const mwrt_model* model,
                                  int32_t nf, const double* frq_ghz,
                                  double* d_awet_out, double* d_adry_out, void* stream);
 
-/* How mwrt_absorption_batch[_device] evaluates a fine spectral grid: 0 = automatic (windowed when the frequency
- * list qualifies: >= 128 strictly increasing frequencies whose 128-frequency windows each span <= 6 GHz), 1 = always
- * every line at every frequency, 2 = windowed or MWRT_ERR_UNSUPPORTED.  Windowed: the lines >= 4 GHz beyond a
- * window are summed at 16 Chebyshev nodes of the window and interpolated (error <= 1e-10 of the line sum), the
- * others are evaluated directly; results agree with mode 1 to ~1e-10 relative. */
+/* How a fine spectral grid is evaluated: 0 = automatic (windowed when the frequency list qualifies: >= 128 strictly
+ * increasing frequencies whose 128-frequency windows each span <= 6 GHz, <= 505 levels, LDS permitting), 1 = always every
+ * line at every frequency, 2 = windowed or MWRT_ERR_UNSUPPORTED.  Windowed: the lines >= 4 GHz beyond a window are summed
+ * at 16 Chebyshev nodes of the window and interpolated (error <= 1e-10 of the line sum), the others are evaluated
+ * directly; results agree with mode 1 to ~1e-10 relative.
+ * Governs mwrt_absorption_batch[_device] and mwrt_layer_tau_batch_device (modes 0, 1, 2 as above), and the TB entry
+ * points' automatic fine-grid path (windowed K1 -> layer optical depth in HBM -> RTE kernel): mode 1 switches that
+ * path off (one fused kernel, every line at every frequency); modes 0 and 2 both leave it automatic -- a TB call is
+ * never refused for its frequency list. */
 int mwrt_set_absorption_mode(mwrt_context* ctx, int mode);
 
 /* The second half of execute() on its own: layer optical depths (exponential_integration, zeroflg = True) +
@@ -241,6 +245,31 @@ int mwrt_tb_from_absorption_device(mwrt_context* ctx, const mwrt_model* model,
                                    int32_t nf, const double* frq_ghz, int32_t nang, const double* elev_deg,
                                    const double* d_awet, const double* d_adry,
                                    double* d_tb_out, uint8_t* d_valid_out, void* stream);
+
+/* The fine-grid two-kernel form with the LAYER OPTICAL DEPTH as the hand-over (what the TB entry points run
+ * automatically on window-eligible frequency lists; BASELINE configs[4]: 1.8 GB per GPU written once, read once):
+ *   mwrt_layer_tau_batch_device   clearsky_absorption + exponential_integration(zeroflg = True) on wet and dry,
+ *                                 summed [EXT, reached from PyRTlib_processing.py:126]: zenith layer optical depth
+ *                                 d_tau_out [nprof][nlev][tau_pitch] in Np (entry [.][0][.] = 0; 8 B per (profile,
+ *                                 level, frequency), FREQUENCY fastest), d_valid_out [nprof] as for mwrt_tb_batch
+ *                                 (a profile flagged 0 or 2 has NaN rows).  tau_pitch = doubles between consecutive
+ *                                 levels: a multiple of 16, >= mwrt_layer_tau_pitch(nf) (= nf rounded up to 16);
+ *                                 columns [nf, tau_pitch) are scratch.  nlev <= 1009.
+ *   mwrt_tb_from_layer_tau_device RTEquation.planck (from_sat = False) + bright [EXT]: TBs [nprof][nang][nf] from such
+ *                                 an array (tau_pitch >= nf), T [nprof][nlev] and d_valid [nprof] (1 = integrate,
+ *                                 anything else = that profile's TBs are NaN).  `model` supplies h, k, t_cosmic.
+ * DEVICE buffers, asynchronous on `stream`. */
+int mwrt_layer_tau_pitch(int32_t nf);
+int mwrt_layer_tau_batch_device(mwrt_context* ctx, const mwrt_model* model,
+                                int64_t nprof, int32_t nlev,
+                                const double* d_z_km, const double* d_p_hpa, const double* d_t_k, const double* d_rh_frac,
+                                int32_t nf, const double* frq_ghz,
+                                double* d_tau_out, int32_t tau_pitch, uint8_t* d_valid_out, void* stream);
+int mwrt_tb_from_layer_tau_device(mwrt_context* ctx, const mwrt_model* model,
+                                  int64_t nprof, int32_t nlev,
+                                  const double* d_tau, int32_t tau_pitch, const double* d_t_k,
+                                  int32_t nf, const double* frq_ghz, int32_t nang, const double* elev_deg,
+                                  const uint8_t* d_valid, double* d_tb_out, void* stream);
 
 /* Diagnostic: evaluates the kernels' own exp / log / division helpers (fexp, flog, fdiv, fdiv1) on
  * host arrays x[n], y_pos[n] (y > 0), so their accuracy can be checked against libm. */

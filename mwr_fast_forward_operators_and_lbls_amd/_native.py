@@ -42,7 +42,7 @@ class MwrtTbOptions(ctypes.Structure):
                 ("reserved0", ctypes.c_int32)]
 
 
-MWRT_VERSION = 200
+MWRT_VERSION = 300
 
 
 #: every symbol include/mwrt.h declares: (name, restype, argtypes)
@@ -73,6 +73,10 @@ SIGNATURES = {
                                                   _vp, _i32, _vp, _vp, _vp, _vp]),
     "mwrt_absorption_batch": (ctypes.c_int, [_vp, _vp, _i64, _i32, _vp, _vp, _vp, _i32, _vp, _vp, _vp]),
     "mwrt_absorption_batch_device": (ctypes.c_int, [_vp, _vp, _i64, _i32, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp]),
+    "mwrt_layer_tau_pitch": (ctypes.c_int, [_i32]),
+    "mwrt_layer_tau_batch_device": (ctypes.c_int, [_vp, _vp, _i64, _i32, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _i32, _vp, _vp]),
+    "mwrt_tb_from_layer_tau_device": (ctypes.c_int, [_vp, _vp, _i64, _i32, _vp, _i32, _vp, _i32, _vp, _i32, _vp, _vp, _vp,
+                                                     _vp]),
     "mwrt_set_absorption_mode": (ctypes.c_int, [_vp, ctypes.c_int]),
     "mwrt_selftest_math": (ctypes.c_int, [_vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp]),
     "mwrt_synchronize": (ctypes.c_int, [_vp, _vp]),
@@ -351,6 +355,26 @@ class Context:
             self._handle, self.model(model), int(nprof), int(nlev), _ptr(d_p), _ptr(d_t), _ptr(d_rh),
             frq.size, _ptr(frq), _ptr(d_awet), _ptr(d_adry),
             _stream(stream)), "mwrt_absorption_batch_device")
+
+    def layer_tau_pitch(self, nf: int) -> int:
+        """Doubles between consecutive levels of a layer-optical-depth array for nf frequencies (multiple of 16)."""
+        return int(self._lib.mwrt_layer_tau_pitch(int(nf)))
+
+    @_serialised
+    def layer_tau_batch_device(self, model, nprof, nlev, d_z, d_p, d_t, d_rh, frq, d_tau, tau_pitch, d_valid, stream=None):
+        """K1 + layer step: zenith layer optical depth [nprof][nlev][tau_pitch] (8 B per point) and valid [nprof]."""
+        frq = _f64(frq).ravel()
+        self._check(self._lib.mwrt_layer_tau_batch_device(
+            self._handle, self.model(model), int(nprof), int(nlev), _ptr(d_z), _ptr(d_p), _ptr(d_t), _ptr(d_rh),
+            frq.size, _ptr(frq), _ptr(d_tau), int(tau_pitch), _ptr(d_valid), _stream(stream)), "mwrt_layer_tau_batch_device")
+
+    @_serialised
+    def tb_from_layer_tau_device(self, model, nprof, nlev, d_tau, tau_pitch, d_t, frq, elev, d_valid, d_tb, stream=None):
+        """K2: downwelling RTE from layer optical depths already in HBM (lane = frequency kernel)."""
+        frq, elev = _f64(frq).ravel(), _f64(elev).ravel()
+        self._check(self._lib.mwrt_tb_from_layer_tau_device(
+            self._handle, self.model(model), int(nprof), int(nlev), _ptr(d_tau), int(tau_pitch), _ptr(d_t), frq.size,
+            _ptr(frq), elev.size, _ptr(elev), _ptr(d_valid), _ptr(d_tb), _stream(stream)), "mwrt_tb_from_layer_tau_device")
 
     @_serialised
     def set_absorption_mode(self, mode: int):

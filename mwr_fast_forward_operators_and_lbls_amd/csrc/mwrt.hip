@@ -12,6 +12,7 @@
 #include <string>
 #include <vector>
 #include <new>
+#include <atomic>
 
 using namespace mwrt;
 
@@ -94,7 +95,7 @@ struct mwrt_context {
   ParamCache frq_cache, am_cache, elev_cache;
   // fine-grid absorption: window descriptors + Lagrange matrices per (model, frequency list), immutable like ParamCache
   int absorption_mode = 0;      // 0 auto, 1 direct, 2 windowed
-  struct WinEntry { const mwrt_model* model; std::vector<double> frq; WinDesc* d_win; double* d_lag; int nwin; };
+  struct WinEntry { uint64_t model_id; std::vector<double> frq; char* d_blob; size_t off_lag, off_lagh, off_masks; int nwin; };
   std::vector<WinEntry> win_cache;
   // ray-tracing workspace: path factors [nprof][nang][nlev] and the per-profile ducting flag
   DevBuf d_amf, d_duct;
@@ -118,6 +119,7 @@ constexpr int TIMING_RING = 512;
 struct mwrt_model {
   ModelFlat* d_desc = nullptr;
   ModelFlat h_desc;
+  uint64_t id = 0;              // process-unique: caches keyed by it survive a destroy / create that reuses the address
 };
 
 namespace {
@@ -298,7 +300,8 @@ int pick_nfc_fused(const mwrt_context* c, int nlev, int nf, int nang) {
 }
 
 // ---- fine-grid absorption: windows of WIN_CHUNKS chunks, Chebyshev nodes, Lagrange matrices ----
-constexpr double WIN_MARGIN_GHZ = 4.0;       // a line is window-far when its centre is this far beyond the window
+constexpr double WIN_MARGIN_GHZ = 4.0;       // an O2 line is window-far when its centre is this far beyond the window (16 nodes)
+constexpr double WIN_H2O_MARGIN_GHZ = 30.0;  // an H2O line: this far (8 nodes; the H2O table is sparse, few lines come closer)
 constexpr double WIN_MAX_SPAN_GHZ = 6.0;     // widest window the 16-node interpolation is used on
 constexpr double WIN_CUTOFF_GUARD_GHZ = 5.0; // the H2O 750-GHz cutoff must be this clearly in or out (pressure shifts < 1 GHz)
 
@@ -314,42 +317,64 @@ bool windows_eligible(const double* frq, int nf) {
   return true;
 }
 
-void build_windows(const mwrt_model_desc& t, const double* frq, int nf, std::vector<WinDesc>* wins, std::vector<double>* lag) {
+// Chebyshev nodes of [flo, fhi] and the barycentric Lagrange weights of every target frequency of the window,
+// stored [chunk][node][target]; targets past the last frequency repeat it (their results are discarded)
+template <int NNODES>
+void window_nodes(const double* frq, int b, int e, double* fnode, double* blk_base) {
+  const int per = WIN_CHUNKS * WIN_NFC;
+  const double flo = frq[b], fhi = frq[e];
+  long double x[NNODES], bw[NNODES];
+  for (int m = 0; m < NNODES; ++m)
+    fnode[m] = (double)(0.5L * (flo + fhi) + 0.5L * (fhi - flo) * cosl(M_PIl * (2 * m + 1) / (2.0L * NNODES)));
+  for (int m = 0; m < NNODES; ++m) x[m] = fnode[m];                // weights for the nodes as the kernel sees them
+  for (int m = 0; m < NNODES; ++m) {
+    long double prod = 1.0L;
+    for (int k = 0; k < NNODES; ++k) if (k != m) prod *= (x[m] - x[k]);
+    bw[m] = 1.0L / prod;
+  }
+  for (int r = 0; r < per; ++r) {
+    const long double f = frq[std::min(b + r, e)];
+    const int cidx = r / WIN_NFC, j = r % WIN_NFC;
+    double* blk = blk_base + (size_t)cidx * NNODES * WIN_NFC;
+    int hit = -1;
+    for (int m = 0; m < NNODES; ++m) if (f == x[m]) hit = m;
+    if (hit >= 0) { blk[hit * WIN_NFC + j] = 1.0; continue; }
+    long double q[NNODES], sum = 0.0L;
+    for (int m = 0; m < NNODES; ++m) { q[m] = bw[m] / (f - x[m]); sum += q[m]; }
+    for (int m = 0; m < NNODES; ++m) blk[m * WIN_NFC + j] = (double)(q[m] / sum);
+  }
+}
+
+// upper bound of a speed-dependent H2O line's half width anywhere in an atmosphere (dry air <= 1100 hPa, vapour
+// <= 150 hPa, T >= 148 K): the host may put such a line in a window's far set only where 10 half-widths cannot
+// reach the window; the kernel re-checks per level and takes the line back if they can
+double sd_halfwidth_bound(const mwrt_model_desc& t, int k) {
+  return t.h2o_w0[k] * 1100.0 * std::pow(2.0, std::max(t.h2o_x[k], 0.0)) +
+         t.h2o_w0s[k] * 150.0 * std::pow(2.0, std::max(t.h2o_xs[k], 0.0));
+}
+
+struct WindowSet {
+  std::vector<WinDesc> wins;
+  std::vector<double> lag, lag_h;       // [nwin][WIN_CHUNKS][nodes][WIN_NFC]
+  std::vector<LineMasks> masks;         // [nchunks]
+};
+
+void build_windows(const mwrt_model_desc& t, const double* frq, int nf, WindowSet* ws) {
   const int per = WIN_CHUNKS * WIN_NFC;
   const int nchunks = (nf + WIN_NFC - 1) / WIN_NFC;
   const int nwin = (nf + per - 1) / per;
-  wins->assign(nwin, WinDesc{});
-  lag->assign((size_t)nwin * per * WIN_NODES, 0.0);
+  ws->wins.assign(nwin, WinDesc{});
+  ws->lag.assign((size_t)nwin * per * WIN_NODES, 0.0);
+  ws->lag_h.assign((size_t)nwin * per * WIN_NODES_H, 0.0);
   for (int w = 0; w < nwin; ++w) {
-    WinDesc& d = (*wins)[w];
+    WinDesc& d = ws->wins[w];
     const int b = w * per, e = std::min(nf, b + per) - 1;
     const double flo = frq[b], fhi = frq[e];
+    d.flo = flo; d.fhi = fhi;
     d.first_chunk = w * WIN_CHUNKS;
     d.nchunks = std::min(WIN_CHUNKS, nchunks - d.first_chunk);
-    long double x[WIN_NODES], bw[WIN_NODES];
-    for (int m = 0; m < WIN_NODES; ++m) {
-      x[m] = 0.5L * (flo + fhi) + 0.5L * (fhi - flo) * cosl(M_PIl * (2 * m + 1) / (2.0L * WIN_NODES));
-      d.fnode[m] = (double)x[m];
-    }
-    for (int m = 0; m < WIN_NODES; ++m) x[m] = d.fnode[m];          // weights for the nodes as the kernel sees them
-    for (int m = 0; m < WIN_NODES; ++m) {
-      long double prod = 1.0L;
-      for (int k = 0; k < WIN_NODES; ++k) if (k != m) prod *= (x[m] - x[k]);
-      bw[m] = 1.0L / prod;
-    }
-    // barycentric Lagrange weights, stored [chunk][node][target]; targets past the last frequency repeat it
-    // (their results are discarded)
-    for (int r = 0; r < per; ++r) {
-      const long double f = frq[std::min(b + r, e)];
-      const int cidx = r / WIN_NFC, j = r % WIN_NFC;
-      double* blk = lag->data() + ((size_t)w * WIN_CHUNKS + cidx) * WIN_NODES * WIN_NFC;
-      int hit = -1;
-      for (int m = 0; m < WIN_NODES; ++m) if (f == x[m]) hit = m;
-      if (hit >= 0) { blk[hit * WIN_NFC + j] = 1.0; continue; }
-      long double q[WIN_NODES], sum = 0.0L;
-      for (int m = 0; m < WIN_NODES; ++m) { q[m] = bw[m] / (f - x[m]); sum += q[m]; }
-      for (int m = 0; m < WIN_NODES; ++m) blk[m * WIN_NFC + j] = (double)(q[m] / sum);
-    }
+    window_nodes<WIN_NODES>(frq, b, e, d.fnode, ws->lag.data() + (size_t)w * per * WIN_NODES);
+    window_nodes<WIN_NODES_H>(frq, b, e, d.fnode_h, ws->lag_h.data() + (size_t)w * per * WIN_NODES_H);
     // which lines are far from the whole window
     for (int k = 0; k < t.n_o2; ++k) {
       const double c = t.o2_f[k];
@@ -357,8 +382,9 @@ void build_windows(const mwrt_model_desc& t, const double* frq, int nf, std::vec
     }
     for (int k = 0; k < t.n_h2o; ++k) {
       const double c = t.h2o_fl[k];
-      if (t.h2o_w2[k] > 0.0) continue;                                 // speed-dependent lines stay direct
-      if (!(c < flo - WIN_MARGIN_GHZ || c > fhi + WIN_MARGIN_GHZ)) continue;
+      if (!(c < flo - WIN_H2O_MARGIN_GHZ || c > fhi + WIN_H2O_MARGIN_GHZ)) continue;
+      // a speed-dependent line stays direct wherever its special shape (inside 10 half-widths) could reach the window
+      if (t.h2o_w2[k] > 0.0 && !(10.0 * sd_halfwidth_bound(t, k) < std::min(std::fabs(c - flo), std::fabs(c - fhi)) - 1.0)) continue;
       const double g = WIN_CUTOFF_GUARD_GHZ;
       const bool d1_in = std::fabs(flo - c) < 750.0 - g && std::fabs(fhi - c) < 750.0 - g;
       const bool d2_in = fhi + c < 750.0 - g;
@@ -368,30 +394,144 @@ void build_windows(const mwrt_model_desc& t, const double* frq, int nf, std::vec
       // anything else (a cutoff crossing the window, or both terms out) is left to the per-chunk loops
     }
   }
+  // line_masks() of every chunk, on the host: the sets depend on the frequencies and the table only
+  ws->masks.assign(nchunks, LineMasks{});
+  for (int ch = 0; ch < nchunks; ++ch) {
+    const int j0 = ch * WIN_NFC, j1 = std::min(nf, j0 + WIN_NFC);
+    LineMasks& lm = ws->masks[ch];
+    for (int k = 0; k < t.n_o2; ++k) {
+      double dmin = 1e300;
+      for (int j = j0; j < j1; ++j) dmin = std::min(dmin, std::fabs(frq[j] - t.o2_f[k]));
+      if (dmin >= FAR_MIN_GHZ + FAR_SHIFT_GHZ) lm.o2_far |= 1ull << k;
+    }
+    for (int k = 0; k < t.n_h2o; ++k) {
+      double dmin = 1e300, smin = 1e300;
+      for (int j = j0; j < j1; ++j) { dmin = std::min(dmin, std::fabs(frq[j] - t.h2o_fl[k])); smin = std::min(smin, std::fabs(frq[j] + t.h2o_fl[k])); }
+      if (dmin >= FAR_H2O_GHZ) lm.h2o_far |= 1u << k;
+      if (dmin >= 750.0 + FAR_H2O_GHZ && smin >= 750.0 + FAR_H2O_GHZ) lm.h2o_none |= 1u << k;
+      if (smin >= 750.0 + FAR_H2O_GHZ) lm.h2o_res |= 1u << k;
+      if (t.h2o_w2[k] > 0.0) lm.h2o_sd |= 1u << k;
+    }
+  }
 }
 
-int get_windows(mwrt_context* c, const mwrt_model* m, const double* frq, int nf, const WinDesc** d_win, const double** d_lag,
-                int* nwin) {
+struct WinPtrs { const WinDesc* win; const double* lag; const double* lag_h; const LineMasks* masks; int nwin; };
+
+int get_windows(mwrt_context* c, const mwrt_model* m, const double* frq, int nf, WinPtrs* out) {
   for (auto& e : c->win_cache)
-    if (e.model == m && (int)e.frq.size() == nf && std::memcmp(e.frq.data(), frq, sizeof(double) * nf) == 0) {
-      *d_win = e.d_win; *d_lag = e.d_lag; *nwin = e.nwin; return MWRT_OK;
+    if (e.model_id == m->id && (int)e.frq.size() == nf && std::memcmp(e.frq.data(), frq, sizeof(double) * nf) == 0) {
+      *out = WinPtrs{(const WinDesc*)e.d_blob, (const double*)(e.d_blob + e.off_lag), (const double*)(e.d_blob + e.off_lagh),
+                     (const LineMasks*)(e.d_blob + e.off_masks), e.nwin};
+      return MWRT_OK;
     }
   if (c->win_cache.size() >= 16) {                      // bounded: drop the oldest entry behind a device-wide drain
     HIP_TRY(hipDeviceSynchronize());
-    (void)hipFree(c->win_cache.front().d_win); (void)hipFree(c->win_cache.front().d_lag);
+    (void)hipFree(c->win_cache.front().d_blob);
     c->win_cache.erase(c->win_cache.begin());
   }
-  std::vector<WinDesc> wins; std::vector<double> lag;
-  build_windows(m->h_desc, frq, nf, &wins, &lag);
-  mwrt_context::WinEntry e{m, std::vector<double>(frq, frq + nf), nullptr, nullptr, (int)wins.size()};
-  HIP_TRY(hipMalloc((void**)&e.d_win, sizeof(WinDesc) * wins.size()));
-  hipError_t err = hipMalloc((void**)&e.d_lag, sizeof(double) * lag.size());
-  if (err == hipSuccess) err = hipMemcpyAsync(e.d_win, wins.data(), sizeof(WinDesc) * wins.size(), hipMemcpyHostToDevice, c->stream);
-  if (err == hipSuccess) err = hipMemcpyAsync(e.d_lag, lag.data(), sizeof(double) * lag.size(), hipMemcpyHostToDevice, c->stream);
+  WindowSet ws;
+  build_windows(m->h_desc, frq, nf, &ws);
+  auto up = [](size_t x) { return (x + 255) & ~(size_t)255; };
+  mwrt_context::WinEntry e{m->id, std::vector<double>(frq, frq + nf), nullptr, 0, 0, 0, (int)ws.wins.size()};
+  e.off_lag = up(sizeof(WinDesc) * ws.wins.size());
+  e.off_lagh = e.off_lag + up(sizeof(double) * ws.lag.size());
+  e.off_masks = e.off_lagh + up(sizeof(double) * ws.lag_h.size());
+  const size_t total = e.off_masks + up(sizeof(LineMasks) * ws.masks.size());
+  std::vector<char> host(total, 0);
+  std::memcpy(host.data(), ws.wins.data(), sizeof(WinDesc) * ws.wins.size());
+  std::memcpy(host.data() + e.off_lag, ws.lag.data(), sizeof(double) * ws.lag.size());
+  std::memcpy(host.data() + e.off_lagh, ws.lag_h.data(), sizeof(double) * ws.lag_h.size());
+  std::memcpy(host.data() + e.off_masks, ws.masks.data(), sizeof(LineMasks) * ws.masks.size());
+  HIP_TRY(hipMalloc((void**)&e.d_blob, total));
+  hipError_t err = hipMemcpyAsync(e.d_blob, host.data(), total, hipMemcpyHostToDevice, c->stream);
   if (err == hipSuccess) err = hipStreamSynchronize(c->stream);
-  if (err != hipSuccess) { (void)hipFree(e.d_win); if (e.d_lag) (void)hipFree(e.d_lag); HIP_TRY(err); }
+  if (err != hipSuccess) { (void)hipFree(e.d_blob); HIP_TRY(err); }
   c->win_cache.push_back(std::move(e));
-  *d_win = c->win_cache.back().d_win; *d_lag = c->win_cache.back().d_lag; *nwin = c->win_cache.back().nwin;
+  const auto& k = c->win_cache.back();
+  *out = WinPtrs{(const WinDesc*)k.d_blob, (const double*)(k.d_blob + k.off_lag), (const double*)(k.d_blob + k.off_lagh),
+                 (const LineMasks*)(k.d_blob + k.off_masks), k.nwin};
+  return MWRT_OK;
+}
+
+// plane-parallel air mass 1 / sin(elev) per elevation (NaN elevation -> NaN air mass: that angle's rows come out NaN)
+int airmass_of(const double* elev, int nang, std::vector<double>* am) {
+  am->resize(nang);
+  for (int a = 0; a < nang; ++a) {
+    // The wrapper tests ang = [elevation_k] per k (PyRTlib_processing.py:106, :117) and skips only that
+    // k: a NaN elevation blanks its own [:, k, :] rows and nothing else.  Its air mass is NaN, which
+    // the slant-path integration carries into every output of that angle; valid[] is about the
+    // profile's own data and stays 1.
+    if (std::isnan(elev[a])) { (*am)[a] = std::nan(""); continue; }
+    // a path at or below the horizon has no plane-parallel air mass
+    if (!(elev[a] > 0.0 && elev[a] < 180.0))
+      return fail(MWRT_ERR_INVALID_ARGUMENT, "elevation angles must lie in (0, 180) degrees");
+    (*am)[a] = 1.0 / std::sin(elev[a] * M_PI / 180.0);
+  }
+  return MWRT_OK;
+}
+
+// ---- fine-grid two-kernel form: K1 + layer step -> zenith layer optical depth in HBM -> RTE ----
+int tau_pitch_of(int nf) { return ((nf + TAU_NFC - 1) / TAU_NFC) * TAU_NFC; }
+
+// can the windowed absorption kernel serve this call (frequency list, level count, LDS)?
+bool windowed_ok(const mwrt_context* c, const double* frq, int nf, int threads) {
+  return windows_eligible(frq, nf) && threads <= 512 && absorb_win_lds_bytes(threads) <= (size_t)c->lds_max;
+}
+
+// K1 (+ layer step): d_tau [nprof][nlev][fpitch], d_valid [nprof].  Windowed kernel when the list qualifies
+// (and the mode allows), else every line at every frequency.
+int layer_tau_launch(mwrt_context* c, const mwrt_model* m, int64_t nprof, int nlev, const double* d_z, const double* d_p,
+                     const double* d_t, const double* d_rh, int nf, const double* frq, const double* dev_frq,
+                     double* d_tau, int fpitch, uint8_t* d_valid, hipStream_t st) {
+  const int threads = tau_threads(nlev);
+  if (threads > 1024) return fail(MWRT_ERR_UNSUPPORTED, "layer optical depths: nlev > 1009");
+  const bool eligible = windowed_ok(c, frq, nf, threads);
+  if (c->absorption_mode == 2 && !eligible)
+    return fail(MWRT_ERR_UNSUPPORTED, "windowed absorption needs >= 128 strictly increasing frequencies in windows <= 6 GHz wide, "
+                                      "<= 505 levels");
+  HIP_TRY(hipMemsetAsync(d_valid, 1, (size_t)nprof, st));
+  TauOut T{d_z, d_tau, d_valid, fpitch};
+  if (eligible && c->absorption_mode != 1) {
+    WinPtrs wp{};
+    int rc = get_windows(c, m, frq, nf, &wp); if (rc) return rc;
+    AbsorbWinArgs w{};
+    w.M = m->d_desc; w.p = d_p; w.t = d_t; w.rh = d_rh; w.frq = dev_frq;
+    w.win = wp.win; w.lagrange = wp.lag; w.lagrange_h = wp.lag_h; w.masks = wp.masks;
+    w.nlev = nlev; w.nf = nf; w.T = T;
+    timing_begin(c, st);
+    hipError_t e = launch_absorb_win(w, dim3((unsigned)nprof, (unsigned)wp.nwin), dim3(threads), st, true);
+    timing_end(c, st);
+    HIP_TRY(e);
+    return MWRT_OK;
+  }
+  AbsorbArgs a{};
+  a.M = m->d_desc; a.p = d_p; a.t = d_t; a.rh = d_rh; a.frq = dev_frq; a.nlev = nlev; a.nf = nf; a.T = T;
+  timing_begin(c, st);
+  hipError_t e = launch_absorb_tau(a, dim3((unsigned)nprof, (unsigned)((nf + TAU_NFC - 1) / TAU_NFC)), dim3(threads), st);
+  timing_end(c, st);
+  HIP_TRY(e);
+  return MWRT_OK;
+}
+
+// K2: TBs from layer optical depths; the elevations go through in groups of <= 8 (or 10) per launch
+int rte_tau_launch(mwrt_context* c, const mwrt_model* m, int64_t nprof, int nlev, const double* d_tau, int fpitch,
+                   const double* d_t, int nf, const double* dev_frq, int nang, const double* dev_am, double* d_tb,
+                   const uint8_t* d_valid, hipStream_t st) {
+  RteTauArgs r{};
+  r.M = m->d_desc; r.tau = d_tau; r.t = d_t; r.frq = dev_frq; r.airmass = dev_am; r.tb = d_tb; r.valid = d_valid;
+  r.nlev = nlev; r.nf = nf; r.nang = nang; r.fpitch = fpitch;
+  const dim3 grid((unsigned)nprof, (unsigned)((nf + RTE_THREADS - 1) / RTE_THREADS));
+  const size_t lds = sizeof(double) * 2 * (size_t)nlev;
+  for (int a0 = 0; a0 < nang;) {
+    const int rem = nang - a0;
+    const int na = rem <= 8 ? rem : (rem == 10 ? 10 : (rem == 9 ? 5 : 8));
+    r.a0 = a0;
+    timing_begin(c, st);
+    hipError_t e = launch_rte_tau(r, grid, lds, st, na);
+    timing_end(c, st);
+    HIP_TRY(e);
+    a0 += na;
+  }
   return MWRT_OK;
 }
 
@@ -438,7 +578,7 @@ int mwrt_destroy(mwrt_context* c) {
   if (!c) return MWRT_OK;
   (void)hipSetDevice(c->device);
   (void)hipStreamSynchronize(c->stream);
-  for (auto& e : c->win_cache) { (void)hipFree(e.d_win); (void)hipFree(e.d_lag); }
+  for (auto& e : c->win_cache) (void)hipFree(e.d_blob);
   c->win_cache.clear();
   c->frq_cache.release(); c->am_cache.release(); c->elev_cache.release(); c->d_amf.release(); c->d_duct.release(); c->d_alpha.release();
   c->d_in.release(); c->d_out.release();
@@ -459,6 +599,8 @@ int mwrt_model_create(mwrt_context* c, const mwrt_model_desc* desc, mwrt_model**
   HIP_TRY(hipSetDevice(c->device));
   mwrt_model* m = new (std::nothrow) mwrt_model();
   if (!m) return fail(MWRT_ERR_OUT_OF_MEMORY, "host allocation failed");
+  static std::atomic<uint64_t> next_id{1};
+  m->id = next_id.fetch_add(1);
   static_cast<mwrt_model_desc&>(m->h_desc) = *desc;
   std::memset(m->h_desc.o2r, 0, sizeof(m->h_desc.o2r));
   std::memset(m->h_desc.h2or, 0, sizeof(m->h_desc.h2or));
@@ -491,8 +633,8 @@ int mwrt_model_destroy(mwrt_context* c, mwrt_model* m) {
     (void)hipSetDevice(c->device);
     (void)hipDeviceSynchronize();                       // launches on any stream may still read the tables / windows
     for (size_t i = c->win_cache.size(); i-- > 0;)      // window descriptors are keyed by the model: drop this one's
-      if (c->win_cache[i].model == m) {
-        (void)hipFree(c->win_cache[i].d_win); (void)hipFree(c->win_cache[i].d_lag);
+      if (c->win_cache[i].model_id == m->id) {
+        (void)hipFree(c->win_cache[i].d_blob);
         c->win_cache.erase(c->win_cache.begin() + (long)i);
       }
   }
@@ -543,20 +685,10 @@ static int tb_launch(mwrt_context* c, int nmodels, const mwrt_model* const* ms, 
     }
     return MWRT_OK;
   }
-  std::vector<double> am(nang);
-  for (int a = 0; a < nang; ++a) {
-    // The wrapper tests ang = [elevation_k] per k (PyRTlib_processing.py:106, :117) and skips only that
-    // k: a NaN elevation blanks its own [:, k, :] rows and nothing else.  Its air mass is NaN, which
-    // the slant-path integration carries into every output of that angle; valid[] is about the
-    // profile's own data and stays 1.
-    if (std::isnan(elev[a])) { am[a] = std::nan(""); continue; }
-    // plane-parallel air mass 1/sin(elev); a path at or below the horizon has none
-    if (!(elev[a] > 0.0 && elev[a] < 180.0))
-      return fail(MWRT_ERR_INVALID_ARGUMENT, "elevation angles must lie in (0, 180) degrees");
-    am[a] = 1.0 / std::sin(elev[a] * M_PI / 180.0);
-  }
+  std::vector<double> am;
+  int rc = airmass_of(elev, nang, &am); if (rc) return rc;
   const double *dev_frq = nullptr, *dev_am = nullptr;
-  int rc = upload_small(c, c->frq_cache, frq, nf, &dev_frq); if (rc) return rc;
+  rc = upload_small(c, c->frq_cache, frq, nf, &dev_frq); if (rc) return rc;
   rc = upload_small(c, c->am_cache, am.data(), nang, &dev_am); if (rc) return rc;
 
   FusedArgs a{};
@@ -568,11 +700,8 @@ static int tb_launch(mwrt_context* c, int nmodels, const mwrt_model* const* ms, 
   if (ex) { a.tbatm = ex->tbatm; a.tmr = ex->tmr; a.tauwet = ex->tauwet; a.taudry = ex->taudry; a.taulay = ex->taulay; }
   a.nlev = nlev; a.nf = nf; a.nang = nang;
   if (ex) { a.tauliq = ex->tauliq; a.tauice = ex->tauice; }
-  if (!use_opt && ex) {                               // clear sky: the cloud columns are plain zeros
-    if (ex->tauliq) HIP_TRY(hipMemsetAsync(ex->tauliq, 0, nout * sizeof(double), st));
-    if (ex->tauice) HIP_TRY(hipMemsetAsync(ex->tauice, 0, nout * sizeof(double), st));
-    a.tauliq = nullptr; a.tauice = nullptr;
-  }
+  // (clear sky: the kernel writes the cloud columns itself -- 0 x air mass for good rows, NaN for blanked profiles
+  // and NaN elevations, like every other column)
   if (cloudy) { a.denliq = opt->denliq; a.denice = opt->denice; }
   if (rays) {
     // RTEquation.refractivity + ray_tracing [EXT] as a pre-kernel on the same stream: path factor ds/dz per
@@ -602,45 +731,34 @@ static int tb_launch(mwrt_context* c, int nmodels, const mwrt_model* const* ms, 
     a.awet_in = d_awet; a.adry_in = d_adry;
     variant = FUSED_FROM_ALPHA;
   }
-  // Fine spectral grids (BASELINE configs[4]): K1 -> alpha -> K2.  The windowed absorption kernel (k_absorb_win) is
-  // ~1.8x the fused kernel's K1 on such grids, which pays for sending the absorption coefficients through HBM once:
-  // profile batches of <= ALPHA_BATCH_BYTES of alpha, absorption kernel then RTE kernel, same stream.
-  if (variant == FUSED_TB_ONLY && nmodels == 1 && c->absorption_mode != 1 && nlev <= 512 && windows_eligible(frq, nf)) {
-    const WinDesc* d_win = nullptr; const double* d_lag = nullptr; int nwin = 0;
-    rc = get_windows(c, ms[0], frq, nf, &d_win, &d_lag, &nwin); if (rc) return rc;
-    const size_t ALPHA_BATCH_BYTES = c->alpha_batch_bytes;
-    const size_t per_prof = (size_t)2 * nf * nlev * sizeof(double);
-    const int64_t batch = std::max<int64_t>(1, std::min<int64_t>(nprof, (int64_t)(ALPHA_BATCH_BYTES / per_prof)));
+  // Fine spectral grids (BASELINE configs[4]): K1 -> tau -> K2.  The windowed absorption kernel (k_absorb_win) is
+  // ~1.8x the fused kernel's K1 on such grids and ends each chunk with the layer step, so what crosses HBM is the
+  // zenith layer optical depth: 8 B per (profile, level, frequency), written once, read once by k_rte_tau
+  // (lane = frequency).  Profile batches of <= alpha_batch_bytes, both kernels on the caller's stream.
+  if (variant == FUSED_TB_ONLY && nmodels == 1 && c->absorption_mode != 1 && windowed_ok(c, frq, nf, tau_threads(nlev))) {
+    const int fpitch = tau_pitch_of(nf);
+    const size_t per_prof = (size_t)nlev * fpitch * sizeof(double);
+    const int64_t batch = std::max<int64_t>(1, std::min<int64_t>(nprof, (int64_t)(c->alpha_batch_bytes / per_prof)));
     bool have_ws = true;
     if ((size_t)batch * per_prof > c->d_alpha.cap) {
       HIP_TRY(hipDeviceSynchronize());                // queued launches may still read the old workspace
       const hipError_t e = c->d_alpha.reserve((size_t)batch * per_prof);
-      if (e == hipErrorOutOfMemory) { (void)hipGetLastError(); have_ws = false; }   // no room for alpha: the fused kernel
+      if (e == hipErrorOutOfMemory) { (void)hipGetLastError(); have_ws = false; }   // no room for tau: the fused kernel
       else HIP_TRY(e);                                                              // needs no workspace at all
     }
     if (have_ws) {
-    rc = workspace_acquire(c, st); if (rc) return rc;
-    const int threads = ((nlev + WAVE - 1) / WAVE) * WAVE;
-    const int nfc2 = pick_nfc_fused(c, nlev, nf, nang);
-    for (int64_t b0 = 0; b0 < nprof; b0 += batch) {
-      const int64_t nb = std::min(batch, nprof - b0);
-      double* aw = c->d_alpha.as<double>();
-      double* ad = aw + (size_t)nb * nf * nlev;
-      AbsorbWinArgs w{};
-      w.M = ms[0]->d_desc; w.p = d_p + b0 * nlev; w.t = d_t + b0 * nlev; w.rh = d_rh + b0 * nlev; w.frq = dev_frq;
-      w.win = d_win; w.lagrange = d_lag; w.awet = aw; w.adry = ad; w.nlev = nlev; w.nf = nf;
-      timing_begin(c, st);
-      hipError_t e = launch_absorb_win(w, dim3((unsigned)nb, (unsigned)nwin), dim3(threads), st);
-      timing_end(c, st);
-      HIP_TRY(e);
-      FusedArgs a2 = a;
-      a2.nprof_in = nb;
-      a2.z = d_z + b0 * nlev; a2.p = nullptr; a2.t = d_t + b0 * nlev; a2.rh = nullptr;
-      a2.tb = d_tb + (size_t)b0 * nang * nf; a2.valid = d_valid + b0;
-      a2.awet_in = aw; a2.adry_in = ad;
-      rc = launch_fused(c, nfc2, a2, nb, st, FUSED_FROM_ALPHA); if (rc) return rc;
-    }
-    return workspace_release(c, st);
+      rc = workspace_acquire(c, st); if (rc) return rc;
+      for (int64_t b0 = 0; b0 < nprof; b0 += batch) {
+        const int64_t nb = std::min(batch, nprof - b0);
+        double* d_tau = c->d_alpha.as<double>();
+        rc = layer_tau_launch(c, ms[0], nb, nlev, d_z + b0 * nlev, d_p + b0 * nlev, d_t + b0 * nlev, d_rh + b0 * nlev, nf, frq,
+                              dev_frq, d_tau, fpitch, d_valid + b0, st);
+        if (rc) return rc;
+        rc = rte_tau_launch(c, ms[0], nb, nlev, d_tau, fpitch, d_t + b0 * nlev, nf, dev_frq, nang, dev_am,
+                            d_tb + (size_t)b0 * nang * nf, d_valid + b0, st);
+        if (rc) return rc;
+      }
+      return workspace_release(c, st);
     }
   }
   rc = launch_fused(c, pick_nfc_fused(c, nlev, nf, nang), a, rows, st, variant);
@@ -801,18 +919,19 @@ int mwrt_absorption_batch_device(mwrt_context* c, const mwrt_model* m, int64_t n
   if (nprof == 0) return MWRT_OK;
   const double* dev_frq = nullptr;
   rc = upload_small(c, c->frq_cache, frq, nf, &dev_frq); if (rc) return rc;
-  const bool eligible = windows_eligible(frq, nf) && nlev <= 512;     // node sums in LDS: 2 x 16 doubles per thread
+  const int wthreads = ((nlev + WAVE - 1) / WAVE) * WAVE;
+  const bool eligible = windowed_ok(c, frq, nf, wthreads);            // node sums in LDS: 2 x 16 doubles per thread
   if (c->absorption_mode == 2 && !eligible)
     return fail(MWRT_ERR_UNSUPPORTED, "windowed absorption needs >= 128 strictly increasing frequencies in windows <= 6 GHz wide");
   if (eligible && c->absorption_mode != 1) {
-    const WinDesc* d_win = nullptr; const double* d_lag = nullptr; int nwin = 0;
-    rc = get_windows(c, m, frq, nf, &d_win, &d_lag, &nwin); if (rc) return rc;
+    WinPtrs wp{};
+    rc = get_windows(c, m, frq, nf, &wp); if (rc) return rc;
     AbsorbWinArgs w{};
-    w.M = m->d_desc; w.p = d_p; w.t = d_t; w.rh = d_rh; w.frq = dev_frq; w.win = d_win; w.lagrange = d_lag;
+    w.M = m->d_desc; w.p = d_p; w.t = d_t; w.rh = d_rh; w.frq = dev_frq;
+    w.win = wp.win; w.lagrange = wp.lag; w.lagrange_h = wp.lag_h; w.masks = wp.masks;
     w.awet = d_awet; w.adry = d_adry; w.nlev = nlev; w.nf = nf;
-    const int threads = ((nlev + WAVE - 1) / WAVE) * WAVE;
     timing_begin(c, st);
-    hipError_t e = launch_absorb_win(w, dim3((unsigned)nprof, (unsigned)nwin), dim3(threads), st);
+    hipError_t e = launch_absorb_win(w, dim3((unsigned)nprof, (unsigned)wp.nwin), dim3(wthreads), st, false);
     timing_end(c, st);
     HIP_TRY(e);
     return MWRT_OK;
@@ -846,6 +965,47 @@ int mwrt_absorption_batch(mwrt_context* c, const mwrt_model* m, int64_t nprof, i
   HIP_TRY(hipMemcpyAsync(adry, dout + nout, nout * sizeof(double), hipMemcpyDeviceToHost, st));
   HIP_TRY(hipStreamSynchronize(st));
   return MWRT_OK;
+}
+
+int mwrt_layer_tau_pitch(int32_t nf) { return nf < 1 ? 0 : tau_pitch_of(nf); }
+
+int mwrt_layer_tau_batch_device(mwrt_context* c, const mwrt_model* m, int64_t nprof, int32_t nlev,
+                                const double* d_z, const double* d_p, const double* d_t, const double* d_rh,
+                                int32_t nf, const double* frq, double* d_tau, int32_t tau_pitch, uint8_t* d_valid,
+                                void* stream) {
+  int rc = check_common(c, m, nprof, nlev, nf);
+  if (rc) return rc;
+  if (!d_z || !d_p || !d_t || !d_rh || !frq || !d_tau || !d_valid) return fail(MWRT_ERR_INVALID_ARGUMENT, "null buffer");
+  if (tau_pitch < tau_pitch_of(nf) || tau_pitch % TAU_NFC != 0)
+    return fail(MWRT_ERR_INVALID_ARGUMENT, "tau_pitch must be a multiple of 16 and >= mwrt_layer_tau_pitch(nf)");
+  if (any_nan(frq, nf)) return fail(MWRT_ERR_INVALID_ARGUMENT, "NaN frequency");
+  HIP_TRY(hipSetDevice(c->device));
+  hipStream_t st = resolve_stream(c, stream);
+  if (nprof == 0) return MWRT_OK;
+  const double* dev_frq = nullptr;
+  rc = upload_small(c, c->frq_cache, frq, nf, &dev_frq); if (rc) return rc;
+  return layer_tau_launch(c, m, nprof, nlev, d_z, d_p, d_t, d_rh, nf, frq, dev_frq, d_tau, tau_pitch, d_valid, st);
+}
+
+int mwrt_tb_from_layer_tau_device(mwrt_context* c, const mwrt_model* m, int64_t nprof, int32_t nlev,
+                                  const double* d_tau, int32_t tau_pitch, const double* d_t,
+                                  int32_t nf, const double* frq, int32_t nang, const double* elev,
+                                  const uint8_t* d_valid, double* d_tb, void* stream) {
+  int rc = check_common(c, m, nprof, nlev, nf);
+  if (rc) return rc;
+  if (nang < 1 || nang > MWRT_MAX_ANGLES) return fail(MWRT_ERR_INVALID_ARGUMENT, "nang out of range");
+  if (!d_tau || !d_t || !frq || !elev || !d_valid || !d_tb) return fail(MWRT_ERR_INVALID_ARGUMENT, "null buffer");
+  if (tau_pitch < nf) return fail(MWRT_ERR_INVALID_ARGUMENT, "tau_pitch < nf");
+  if (any_nan(frq, nf)) return fail(MWRT_ERR_INVALID_ARGUMENT, "NaN frequency");
+  HIP_TRY(hipSetDevice(c->device));
+  hipStream_t st = resolve_stream(c, stream);
+  if (nprof == 0) return MWRT_OK;
+  std::vector<double> am;
+  rc = airmass_of(elev, nang, &am); if (rc) return rc;
+  const double *dev_frq = nullptr, *dev_am = nullptr;
+  rc = upload_small(c, c->frq_cache, frq, nf, &dev_frq); if (rc) return rc;
+  rc = upload_small(c, c->am_cache, am.data(), nang, &dev_am); if (rc) return rc;
+  return rte_tau_launch(c, m, nprof, nlev, d_tau, tau_pitch, d_t, nf, dev_frq, nang, dev_am, d_tb, d_valid, st);
 }
 
 int mwrt_set_absorption_mode(mwrt_context* c, int mode) {

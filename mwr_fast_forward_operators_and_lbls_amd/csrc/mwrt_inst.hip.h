@@ -24,6 +24,10 @@ MWRT_DECLARE_INST(14)
 MWRT_DECLARE_INST(16)
 #undef MWRT_DECLARE_INST
 // the windowed fine-grid absorption kernel exists for the 16-wide chunks only (csrc/mwrt_inst.hip, NFC = 16 unit)
-hipError_t launch_absorb_win(const AbsorbWinArgs& a, dim3 grid, dim3 block, hipStream_t st);
+hipError_t launch_absorb_win(const AbsorbWinArgs& a, dim3 grid, dim3 block, hipStream_t st, bool tau);
+size_t absorb_win_lds_bytes(int threads);
+// ... and so do the layer-optical-depth form of the every-line absorption kernel and the RTE kernel that reads it
+hipError_t launch_absorb_tau(const AbsorbArgs& a, dim3 grid, dim3 block, hipStream_t st);
+hipError_t launch_rte_tau(const RteTauArgs& a, dim3 grid, size_t lds, hipStream_t st, int na);
 
 }  // namespace mwrt

@@ -61,7 +61,8 @@ __device__ __forceinline__ int div_small(int n, int d, unsigned magic) {
 #define MWRT_EXACT_DIV 0
 #endif
 // timing-only ablation builds (tools/ablate.sh): bit 1 skips the O2 line loop, 2 the H2O Lorentz
-// loop, 4 the speed-dependent loop, 8 the K2 integration.  Always 0 in the shipped library.
+// loop, 4 the speed-dependent loop, 8 the K2 integration, 16 the layer step of the TAU absorption kernels, 32 their
+// stores.  Always 0 in the shipped library.
 #ifndef MWRT_ABLATE
 #define MWRT_ABLATE 0
 #endif
@@ -223,6 +224,10 @@ __device__ __forceinline__ double fdiv1(double x, double d) {
 // re-read by broadcast each line iteration; the fence stops the compiler hoisting the reads
 // back into (vector) registers across the line loop.
 #define LDS_RELOAD_FENCE() asm volatile("" ::: "memory")
+// A wave-uniform if / else whose sides are both free of side effects gets flattened by the optimiser into "evaluate
+// both, select" -- the opposite of what a wave vote is for.  An empty volatile asm cannot be speculated: placed at the
+// top of each side it keeps the branch a branch.
+#define KEEP_BRANCH() asm volatile("")
 
 // "Far" lines: every frequency of the chunk is at least FAR_MIN_GHZ (+ the shift allowance) away
 // from the line centre, so D1*D2 may be formed as a polynomial in f^2 without harmful cancellation.
@@ -523,7 +528,13 @@ __device__ __forceinline__ void h2o_absorb(cmodel M, const LevelState& L, const 
     fl.A2 = 2.0 * __builtin_fma(-q.c1, q.c1, q.wsq);
     fl.Bc = cc * cc;
     double P = 2.0 * q.sw, bs = 2.0 * q.sbase;
-    if (!__all(d1_in && d2_in)) {                                                // cutoff not uniform: loop B's job
+    bool plain = d1_in && d2_in;
+    if constexpr (NODES) {
+      // a speed-dependent line may sit in the window-far set only where its special shape (inside 10 half-widths,
+      // ABH2O_SD) is out of reach of the whole window at this level
+      if (M->h2o_w2[k] > 0.0) plain = plain && (10.0 * q.w0 < ::fmin(fabs(q.c1 - fmin), fabs(q.c1 - fmax)));
+    }
+    if (!__all(plain)) {                                                         // cutoff not uniform: loop B's job
       if constexpr (NODES) *failed |= 1u << k; else deferred |= 1u << k;
       P = 0.0; bs = 0.0;
     }
@@ -549,6 +560,9 @@ __device__ __forceinline__ void h2o_absorb(cmodel M, const LevelState& L, const 
     const bool d2_in = fmax + q.c1 < 750.0 && fmin + q.c1 > -750.0;
     const bool d2_out = fmin + q.c1 >= 750.0;
     if (__all(d1_out && d2_out)) continue;
+    if constexpr (NODES) {                                     // a speed-dependent line within reach of its special shape: not here
+      if (M->h2o_w2[k] > 0.0 && !__all(10.0 * q.w0 < ::fmin(fabs(q.c1 - fmin), fabs(q.c1 - fmax)))) { *failed |= 1u << k; continue; }
+    }
     LDS_RELOAD_FENCE();
     if (__all(d1_in && d2_in)) {                               // next to a line centre: detunings formed directly
       bsum = __builtin_fma(2.0, q.sbase, bsum);
@@ -822,43 +836,123 @@ __device__ __forceinline__ void dry_absorb(cmodel M, const LevelState& L, const 
 // (frexp, second division, series) and a third division.  It is also better conditioned than the
 // quotient form, which loses up to 1e-7 relative when x1 - x0 is just above the 1e-9 switch.
 constexpr double LOGMEAN_SMALL_S = 0.1715;      // |s| <= this: series truncation < 1.1e-19
+
+// s / atanh(s) = 1 - z/3 - 4 z^2/45 - 44 z^3/945 - ... (z = s^2; coefficients by series inversion, truncation after
+// z^10 < 1.1e-19 at |s| = 0.1715): the log-mean is (x1 + x0)/2 times this
+__device__ __forceinline__ double s_over_atanh(double z) {
+  double q = -8.2312065673505011548e-03;
+  MWRT_FMA_SC(q, z, -9.5160731945278989134e-03);
+  MWRT_FMA_SC(q, z, -1.1203745637718733130e-02);
+  MWRT_FMA_SC(q, z, -1.3502765051265933100e-02);
+  MWRT_FMA_SC(q, z, -1.6787551856334925118e-02);
+  MWRT_FMA_SC(q, z, -2.1796804019026241248e-02);
+  MWRT_FMA_SC(q, z, -3.0194003527336860670e-02);
+  MWRT_FMA_SC(q, z, -4.6560846560846560847e-02);
+  MWRT_FMA_SC(q, z, -8.8888888888888888889e-02);
+  MWRT_FMA_SC(q, z, -3.3333333333333333333e-01);
+  return __builtin_fma(q, z, 1.0);
+}
+
+// The log-mean for ANY ratio of two positive values with one division for the logarithm and one for the quotient:
+//   x1/x0 = 2^e m,  m in [1/sqrt 2, sqrt 2]  (e from the exponent fields, x0' = x0 2^e),
+//   s' = (x1 - x0')/(x1 + x0'),  ln(x1/x0) = e ln 2 + 2 s' (atanh(s')/s'),  result = (x1 - x0) / ln(x1/x0).
+// ln keeps full RELATIVE accuracy as x1 -> x0 (e = 0, ln = 2 s' (1 + z/3 + ...)), which the quotient of a generic
+// log cannot.  ~45 VALU, no branch: what a wave runs when some lane's levels are far apart (the coarse top of a
+// sounding shares its wave with finely spaced levels).
+__device__ __forceinline__ double log_mean_any(double x1, double x0, double d) {
+  int e = __builtin_amdgcn_frexp_exp(x1) - __builtin_amdgcn_frexp_exp(x0);
+  double x0s = __builtin_amdgcn_ldexp(x0, e);                      // x1 / x0s in (1/2, 2)
+  const bool hi = x1 > 1.41421356237309504880 * x0s;
+  const bool lo = x1 * 1.41421356237309504880 < x0s;
+  x0s = hi ? x0s + x0s : (lo ? 0.5 * x0s : x0s);
+  e = hi ? e + 1 : (lo ? e - 1 : e);
+  const double sp = fdiv1(x1 - x0s, x1 + x0s);                     // |s'| <= 0.1716
+  const double z = sp * sp;
+  double p = 9.5238095238095233e-02;                               // 2/21: 2 atanh(s)/s = 2 + 2z/3 + 2z^2/5 + ...
+  MWRT_FMA_SC(p, z, 1.0526315789473684e-01);
+  MWRT_FMA_SC(p, z, 1.1764705882352941e-01);
+  MWRT_FMA_SC(p, z, 1.3333333333333333e-01);
+  MWRT_FMA_SC(p, z, 1.5384615384615385e-01);
+  MWRT_FMA_SC(p, z, 1.8181818181818182e-01);
+  MWRT_FMA_SC(p, z, 2.2222222222222221e-01);
+  MWRT_FMA_SC(p, z, 2.8571428571428570e-01);
+  MWRT_FMA_SC(p, z, 4.0000000000000002e-01);
+  MWRT_FMA_SC(p, z, 6.6666666666666663e-01);
+  p = __builtin_fma(p, z, 2.0);
+  const double ed = (double)e;
+  const double ln = __builtin_fma(ed, 6.93147180369123816490e-01, __builtin_fma(ed, 1.90821492927058770002e-10, sp * p));
+  return fdiv1(d, ln);
+}
+
 template <bool ZEROFLG = true>
 __device__ __forceinline__ double layer_value(double x1, double x0, bool& neg, bool live = true) {
   // live = this lane holds a layer (its result is used): the wave votes ignore the others
   const double d = x1 - x0;
   const double sm = x1 + x0;
-  const bool negative = (x0 < 0.0) | (x1 < 0.0);
   const bool same = fabs(d) < 1e-09;
-  const bool zero = x0 == 0.0 || x1 == 0.0;
-  const bool special = live && (negative || same || zero);
+  // x0 < 0 | x1 < 0 | x0 == 0 | x1 == 0 in one comparison (NaN inputs never reach this point)
+  const bool nonpos = !(fmin(x1, x0) > 0.0);
+  const bool special = live && (nonpos || same);
   double r;
   const double s = fdiv1(d, sm);
   if (__all(!live || special || fabs(s) <= LOGMEAN_SMALL_S)) {
-    // s / atanh(s) = 1 - z/3 - 4 z^2/45 - 44 z^3/945 - ... (z = s^2; coefficients by series inversion,
-    // truncation after z^10 < 1.1e-19 at |s| = 0.1715): the log-mean is (x1 + x0)/2 times this
-    const double z = s * s;
-    double q = -8.2312065673505011548e-03;
-    MWRT_FMA_SC(q, z, -9.5160731945278989134e-03);
-    MWRT_FMA_SC(q, z, -1.1203745637718733130e-02);
-    MWRT_FMA_SC(q, z, -1.3502765051265933100e-02);
-    MWRT_FMA_SC(q, z, -1.6787551856334925118e-02);
-    MWRT_FMA_SC(q, z, -2.1796804019026241248e-02);
-    MWRT_FMA_SC(q, z, -3.0194003527336860670e-02);
-    MWRT_FMA_SC(q, z, -4.6560846560846560847e-02);
-    MWRT_FMA_SC(q, z, -8.8888888888888888889e-02);
-    MWRT_FMA_SC(q, z, -3.3333333333333333333e-01);
-    q = __builtin_fma(q, z, 1.0);
-    r = (0.5 * sm) * q;
+    KEEP_BRANCH();
+    r = (0.5 * sm) * s_over_atanh(s * s);
   } else {
-    r = fdiv1(d, flog(fdiv(x1, x0)));
+    KEEP_BRANCH();
+    r = log_mean_any(x1, x0, d);
   }
   if (__any(special)) {                                        // rare below the stratosphere: wave-uniform skip (and 12 VGPRs fewer live)
+    const bool negative = (x0 < 0.0) | (x1 < 0.0);
+    const bool zero = x0 == 0.0 || x1 == 0.0;
     if (negative && live) neg = true;
     r = zero ? (ZEROFLG ? sm * 0.5 : 0.0) : r;                 // zeroflg = True for wet & dry, False for liquid & ice
     r = same ? x1 : r;
     r = negative ? 0.0 : r;
   }
   return r;
+}
+
+// Four layer values behind ONE pair of wave votes (the TAU absorption kernels make 32 per lane and chunk).
+// x1[k] in, layer value out (in place); x0[k] = the level below.
+template <bool ZEROFLG = true>
+__device__ __forceinline__ void layer_value4(double (&x1)[4], const double (&x0)[4], bool& neg, bool live) {
+  double s[4];
+  bool small = true, special = false;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const double d = x1[k] - x0[k];
+    const bool sp = !(fmin(x1[k], x0[k]) > 0.0) || fabs(d) < 1e-09;
+    s[k] = fdiv1(d, x1[k] + x0[k]);
+    special = special || sp;
+    small = small && (sp || fabs(s[k]) <= LOGMEAN_SMALL_S);
+  }
+  special = special && live;
+  double r[4];
+  if (__all(!live || small)) {
+    KEEP_BRANCH();
+#pragma unroll
+    for (int k = 0; k < 4; ++k) r[k] = (0.5 * (x1[k] + x0[k])) * s_over_atanh(s[k] * s[k]);
+  } else {
+    KEEP_BRANCH();
+#pragma unroll
+    for (int k = 0; k < 4; ++k) r[k] = log_mean_any(x1[k], x0[k], x1[k] - x0[k]);
+  }
+  if (__any(special)) {
+    KEEP_BRANCH();
+#pragma unroll 1
+    for (int k = 0; k < 4; ++k) {
+      const double d = x1[k] - x0[k];
+      const bool negative = (x0[k] < 0.0) | (x1[k] < 0.0);
+      const bool zero = x0[k] == 0.0 || x1[k] == 0.0;
+      if (negative && live) neg = true;
+      double q = zero ? (ZEROFLG ? (x1[k] + x0[k]) * 0.5 : 0.0) : r[k];
+      q = (fabs(d) < 1e-09) ? x1[k] : q;
+      r[k] = negative ? 0.0 : q;
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < 4; ++k) x1[k] = r[k];
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1534,57 +1628,152 @@ k_tb_fused(const FusedArgs A) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// K1 alone: awet / adry [nprof][nf][nlev] (RTEquation.clearsky_absorption [EXT])
+// K1 alone: awet / adry [nprof][nf][nlev] (RTEquation.clearsky_absorption [EXT]) -- or, TAU = true, K1 + the layer
+// step: zenith layer optical depth tau [nprof][nlev][fpitch] (exponential_integration(zeroflg = True) on wet and
+// dry, summed), 8 B per (profile, level, frequency) instead of 16, frequency fastest: what k_rte_tau reads with
+// lane = frequency.
+//
+// TAU-mode level mapping.  The layer step needs level i-1 next to level i.  Lanes are levels, so the neighbour is
+// one lane down (a DPP shift, no LDS) -- except across wave seams.  Instead of passing seam values through LDS
+// behind a workgroup barrier, each wave REPEATS the last level of the wave below in its lane 0:
+//     level(wave, lane) = 63 * wave + lane,    lane 0 of waves >= 1 is a duplicate that stores nothing.
+// 3 waves cover 190 levels (the reference's 180), and the waves of a workgroup never wait for each other inside
+// the frequency loop.
 // ---------------------------------------------------------------------------------------------
+constexpr int TAU_NFC = 16;                   // tau rows are written in 16-frequency (128-byte) pieces
+__host__ __device__ constexpr int tau_threads(int nlev) { return ((nlev - 1 + (WAVE - 2)) / (WAVE - 1)) * WAVE; }
+
+struct TauOut {
+  const double* z;         // [nprof][nlev] km (layer thickness)
+  double* tau;             // [nprof][nlev][fpitch]; row 0 (the ground level) is 0
+  uint8_t* valid;          // [nprof], preset to 1 by the host; lowered to 0 (NaN input) / raised to 2 (negative absorption)
+  int fpitch;              // doubles between consecutive levels: a multiple of 16, >= 16 * ceil(nf / 16)
+};
+
+// value of lane - 1 (lane 0 keeps its own): GFX9 wave_shr:1, two v_mov_b32_dpp, no LDS crossbar
+__device__ __forceinline__ double lane_below(double v) {
+  const long long b = __builtin_bit_cast(long long, v);
+  const int lo = (int)b, hi = (int)(b >> 32);
+  const int plo = __builtin_amdgcn_update_dpp(lo, lo, 0x138, 0xf, 0xf, false);
+  const int phi = __builtin_amdgcn_update_dpp(hi, hi, 0x138, 0xf, 0xf, false);
+  return __builtin_bit_cast(double, ((long long)phi << 32) | (unsigned)plo);
+}
+
+// the chunk's frequency table {f, f^2} x NFC, {fmin, fmax}, N2 factor x NFC in a WAVE-PRIVATE piece of LDS: filled
+// and read by the same wave, so no workgroup barrier separates consecutive chunks
+template <int NFC, class ModelPtr>
+__device__ __forceinline__ void fill_chunk_table(double* sfq, ModelPtr M, cdoubles cfrq, int jbase, int nfc, int lane) {
+  __builtin_amdgcn_wave_barrier();
+  asm volatile("" ::: "memory");                      // the previous chunk's reads stay above the refill
+  if (lane < NFC) {
+    const double f = cfrq[jbase + min(lane, nfc - 1)];
+    sfq[2 * lane] = f; sfq[2 * lane + 1] = f * f;
+    double fdep = 1.0;
+    if (M->n2_fdep) { const double q = f * (1.0 / 450.0); fdep = 0.5 + fdiv(0.5, 1.0 + q * q); }
+    sfq[2 * NFC + 2 + lane] = fdep;
+  }
+  if (lane == WAVE - 1) {
+    double lo = cfrq[jbase], hi = lo;
+    for (int j = 1; j < nfc; ++j) { const double f = cfrq[jbase + j]; lo = fmin(lo, f); hi = fmax(hi, f); }
+    sfq[2 * NFC] = lo; sfq[2 * NFC + 1] = hi;
+  }
+  __builtin_amdgcn_wave_barrier();
+  asm volatile("" ::: "memory");
+}
+
+// NaN rows for chunks [c0, c0 + nch) of one profile (NaN input, negative absorption): k_rte_tau turns them into NaN TBs
+__device__ __forceinline__ void blank_tau(const TauOut& T, int64_t prof, int nlev, int c0, int nch, int tid, int nthreads) {
+  const double qnan = __builtin_nan("");
+  const int w = nch * TAU_NFC;
+  for (int it = tid; it < nlev * w; it += nthreads) {
+    const int l = it / w, k = it - l * w;
+    T.tau[(prof * nlev + l) * (int64_t)T.fpitch + c0 * TAU_NFC + k] = qnan;
+  }
+}
+
 struct AbsorbArgs {
   const ModelFlat* M;
   const double* p; const double* t; const double* rh;
   const double* frq;
   double* awet; double* adry;
   int nlev, nf;
+  TauOut T;                // TAU instantiations only
 };
 
-template <int NFC, int MAXT>
+template <int NFC, int MAXT, bool TAU = false>
 __global__ void __launch_bounds__(MAXT)
 k_absorb(const AbsorbArgs A) {
+  static_assert(!TAU || NFC == TAU_NFC, "tau rows are written in 16-frequency pieces");
   const int tid = threadIdx.x;
+  const int lane = tid & (WAVE - 1), wave = tid / WAVE;
   const int64_t prof = blockIdx.x;
   const int jbase = blockIdx.y * NFC;
   const int nfc = min(NFC, A.nf - jbase);
   const cmodel M = (cmodel)A.M;
   const cdoubles cfrq = (cdoubles)A.frq;
-  __shared__ double sfq[3 * NFC + 2];
-  if (tid < NFC) {
-    const double f = cfrq[jbase + min(tid, nfc - 1)];
-    sfq[2 * tid] = f; sfq[2 * tid + 1] = f * f;
-    double fdep = 1.0;
-    if (M->n2_fdep) { const double q = f * (1.0 / 450.0); fdep = 0.5 + fdiv(0.5, 1.0 + q * q); }
-    sfq[2 * NFC + 2 + tid] = fdep;
-  }
-  if (tid == WAVE - 1) {
-    double lo = cfrq[jbase], hi = lo;
-    for (int j = 1; j < nfc; ++j) { const double f = cfrq[jbase + j]; lo = fmin(lo, f); hi = fmax(hi, f); }
-    sfq[2 * NFC] = lo; sfq[2 * NFC + 1] = hi;
-  }
-  __syncthreads();
-  const bool active = tid < A.nlev;
-  const int64_t off = prof * A.nlev + (active ? tid : 0);
+  __shared__ double sfq_w[MAXT / WAVE][3 * NFC + 2];
+  double* sfq = sfq_w[wave];
+  fill_chunk_table<NFC>(sfq, M, cfrq, jbase, nfc, lane);
+  const int lev = TAU ? wave * (WAVE - 1) + lane : tid;
+  const bool active = lev < A.nlev;
+  const int64_t off = prof * A.nlev + (active ? lev : 0);
   const double pi = A.p[off], ti = A.t[off], rhi = A.rh[off];
+  double zi = 0.0;
+  if constexpr (TAU) {
+    zi = A.T.z[off];
+    if (__syncthreads_or(active && (isnan(zi) || isnan(pi) || isnan(ti) || isnan(rhi)))) {   // check_for_nans
+      blank_tau(A.T, prof, A.nlev, blockIdx.y, 1, tid, blockDim.x);
+      if (tid == 0) A.T.valid[prof] = 0;
+      return;
+    }
+  }
   double awet[NFC], adry[NFC];
   const double e = goff_gratch_e(ti, rhi);
   const LevelState L = level_state(pi, ti, e);
-  const int lane = tid & (WAVE - 1);
   const LineMasks lm = line_masks(M, sfq, NFC, lane);
   h2o_absorb<NFC>(M, L, sfq, lm, awet);
   dry_absorb<NFC>(M, L, sfq, lm, adry);
-  if (active) {
+  if constexpr (!TAU) {
+    if (active) {
 #pragma unroll
-    for (int j = 0; j < NFC; ++j) {
-      if (j < nfc) {
-        const int64_t o = (prof * A.nf + jbase + j) * A.nlev + tid;
-        A.awet[o] = awet[j];
-        A.adry[o] = adry[j];
+      for (int j = 0; j < NFC; ++j) {
+        if (j < nfc) {
+          const int64_t o = (prof * A.nf + jbase + j) * A.nlev + tid;
+          A.awet[o] = awet[j];
+          A.adry[o] = adry[j];
+        }
       }
+    }
+  } else {
+    const bool has_prev = active && lev > 0 && lane > 0;
+    const double z0 = A.T.z[prof * A.nlev];
+    const double dz = has_prev ? ((zi - z0) - (A.T.z[off - 1] - z0)) : 0.0;
+    bool neg = false;
+    double tz[NFC];
+#pragma unroll
+    for (int j = 0; j < NFC; j += 4) {
+#pragma clang fp contract(off)               // wet * dz + dry * dz rounds as in the fused kernel
+      double w4[4] = {awet[j], awet[j + 1], awet[j + 2], awet[j + 3]};
+      double d4[4] = {adry[j], adry[j + 1], adry[j + 2], adry[j + 3]};
+      const double wb[4] = {lane_below(w4[0]), lane_below(w4[1]), lane_below(w4[2]), lane_below(w4[3])};
+      const double db[4] = {lane_below(d4[0]), lane_below(d4[1]), lane_below(d4[2]), lane_below(d4[3])};
+      layer_value4(w4, wb, neg, has_prev);
+      layer_value4(d4, db, neg, has_prev);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const double twj = has_prev ? w4[k] * dz : 0.0;
+        const double tdj = has_prev ? d4[k] * dz : 0.0;
+        tz[j + k] = twj + tdj;
+      }
+    }
+    if (active && (lane > 0 || wave == 0)) {
+      double2* row = (double2*)(A.T.tau + (prof * A.nlev + lev) * (int64_t)A.T.fpitch + jbase);
+#pragma unroll
+      for (int j = 0; j < NFC; j += 2) row[j / 2] = double2{tz[j], tz[j + 1]};
+    }
+    if (__syncthreads_or(neg)) {              // pyrtlib raises ValueError here: flag 2, NaN out
+      blank_tau(A.T, prof, A.nlev, blockIdx.y, 1, tid, blockDim.x);
+      if (tid == 0) A.T.valid[prof] = 2;
     }
   }
 }
@@ -1602,15 +1791,22 @@ k_absorb(const AbsorbArgs A) {
 // the far lines is paid once per window instead of once per chunk.
 // Interpolation error: <= 1e-10 of the line sum for spans <= 6 GHz (16 nodes, 4 GHz margin; tools/window_probe.py
 // reproduces the bound on the oracle), i.e. invisible against the 1e-6 K parity bar -- and tested against it.
+//
+// TAU = true: the chunk ends with the layer step (see k_absorb) and writes the zenith layer optical depth,
+// [level][frequency], 8 B per point; the fine-grid TB path is this kernel followed by k_rte_tau.
 // ---------------------------------------------------------------------------------------------
-constexpr int WIN_NODES = 16;
+constexpr int WIN_NODES = 16;          // O2: lines from WIN_MARGIN_GHZ beyond the window
+constexpr int WIN_NODES_H = 8;         // H2O: lines from WIN_H2O_MARGIN_GHZ beyond it -- so smooth across the window that 8
+                                       // nodes do (convergence ~ 25^-n); a third less LDS = a fourth workgroup per CU
 constexpr int WIN_CHUNKS = 8;
 constexpr int WIN_NFC = 16;
 
 struct WinDesc {                       // one per window, built by the host (csrc/mwrt.hip: build_windows)
   double fnode[WIN_NODES];             // Chebyshev nodes of [f_lo, f_hi], GHz
+  double fnode_h[WIN_NODES_H];
+  double flo, fhi;                     // the window itself
   unsigned long long o2_far;           // O2 lines >= WIN_MARGIN_GHZ beyond the window
-  unsigned h2o_far_both, h2o_far_res;  // H2O lines >= the margin beyond the window with a cutoff state uniform across it
+  unsigned h2o_far_both, h2o_far_res;  // H2O lines >= WIN_H2O_MARGIN_GHZ beyond the window with a cutoff state uniform across it
   int first_chunk, nchunks;            // chunks [first_chunk, first_chunk + nchunks) of the frequency list
   int pad0, pad1;
 };
@@ -1621,37 +1817,59 @@ struct AbsorbWinArgs {
   const double* frq;
   const WinDesc* win;                  // [nwin]
   const double* lagrange;              // [nwin][WIN_CHUNKS][WIN_NODES][WIN_NFC]: weight of node m for target j of chunk c
+  const double* lagrange_h;            // [nwin][WIN_CHUNKS][WIN_NODES_H][WIN_NFC]
+  const LineMasks* masks;              // [nchunks of the list]: line_masks() of every chunk, precomputed (it depends on the
+                                       // frequencies and the table only)
   double* awet; double* adry;
   int nlev, nf;
+  TauOut T;                            // TAU instantiations only
 };
 
-template <int MAXT>
+template <int MAXT, bool TAU = false>
 __global__ void __launch_bounds__(MAXT, (MAXT <= 256 ? 3 : 1))
 k_absorb_win(const AbsorbWinArgs A) {
-  constexpr int NFC = WIN_NFC, NN = WIN_NODES;
+  constexpr int NFC = WIN_NFC, NN = WIN_NODES, NH = WIN_NODES_H;
   static_assert(NN == NFC, "the node set is evaluated through the NFC-wide line bodies");
-  const int tid = threadIdx.x, lane = tid & (WAVE - 1);
+  static_assert(NFC == TAU_NFC, "tau rows are written in 16-frequency pieces");
+  const int tid = threadIdx.x, lane = tid & (WAVE - 1), wave = tid / WAVE;
   const int64_t prof = blockIdx.x;
   const cmodel M = (cmodel)A.M;
   const cdoubles cfrq = (cdoubles)A.frq;
   typedef const __attribute__((address_space(4))) WinDesc* cwin;
   const cwin D = (cwin)(A.win + blockIdx.y);
   const cdoubles Lw = (cdoubles)(A.lagrange + (size_t)blockIdx.y * WIN_CHUNKS * NFC * NN);
+  const cdoubles Lwh = (cdoubles)(A.lagrange_h + (size_t)blockIdx.y * WIN_CHUNKS * NFC * NH);
+  typedef const __attribute__((address_space(4))) LineMasks* cmasks;
+  const cmasks CM = (cmasks)A.masks;
   __shared__ double sfn[3 * NFC + 2];                        // the nodes, laid out like a chunk
-  __shared__ double sfq[3 * NFC + 2];
+  __shared__ double sfn_h[3 * NH + 2];                       // the H2O nodes
+  __shared__ double sfq_w[MAXT / WAVE][3 * NFC + 2];         // the current chunk, one copy per wave (fill_chunk_table)
+  double* sfq = sfq_w[wave];
   if (tid < NN) {
     const double f = D->fnode[tid];
     sfn[2 * tid] = f; sfn[2 * tid + 1] = f * f; sfn[2 * NFC + 2 + tid] = 1.0;
   }
-  if (tid == WAVE - 1) {
-    double lo = D->fnode[0], hi = lo;
-    for (int j = 1; j < NN; ++j) { const double f = D->fnode[j]; lo = fmin(lo, f); hi = fmax(hi, f); }
-    sfn[2 * NFC] = lo; sfn[2 * NFC + 1] = hi;
+  if (tid >= NN && tid < NN + NH) {                          // (a one-wave workgroup has lanes 16 .. 23 too)
+    const double f = D->fnode_h[tid - NN];
+    sfn_h[2 * (tid - NN)] = f; sfn_h[2 * (tid - NN) + 1] = f * f; sfn_h[2 * NH + 2 + (tid - NN)] = 1.0;
   }
-  __syncthreads();
-  const bool active = tid < A.nlev;
-  const int64_t off = prof * A.nlev + (active ? tid : 0);
+  if (tid == WAVE - 1) {                                     // cutoff / range votes at the nodes speak for the whole window
+    sfn[2 * NFC] = D->flo; sfn[2 * NFC + 1] = D->fhi;
+    sfn_h[2 * NH] = D->flo; sfn_h[2 * NH + 1] = D->fhi;
+  }
+  const int lev = TAU ? wave * (WAVE - 1) + lane : tid;
+  const bool active = lev < A.nlev;
+  const int64_t off = prof * A.nlev + (active ? lev : 0);
   const double pi = A.p[off], ti = A.t[off], rhi = A.rh[off];
+  const int nch = D->nchunks;
+  double zi = 0.0;
+  bool bad = false;
+  if constexpr (TAU) { zi = A.T.z[off]; bad = active && (isnan(zi) || isnan(pi) || isnan(ti) || isnan(rhi)); }
+  if (__syncthreads_or(bad)) {                               // (also publishes sfn) check_for_nans: NaN out, valid = 0
+    blank_tau(A.T, prof, A.nlev, D->first_chunk, nch, tid, blockDim.x);
+    if (tid == 0) A.T.valid[prof] = 0;
+    return;
+  }
   const double e = goff_gratch_e(ti, rhi);
   const LevelState L = level_state(pi, ti, e);
 
@@ -1660,8 +1878,8 @@ k_absorb_win(const AbsorbWinArgs A) {
   // registers: 32 doubles per lane would cost the kernel two waves of occupancy.
   extern __shared__ __attribute__((aligned(16))) double wlds[];
   const int nthreads = blockDim.x;
-  double* Sh_l = wlds;                                        // [NN][nthreads]
-  double* So_l = wlds + (size_t)NN * nthreads;
+  double* Sh_l = wlds;                                        // [NH][nthreads]
+  double* So_l = wlds + (size_t)NH * nthreads;                // [NN][nthreads]
   const unsigned wf_both = D->h2o_far_both, wf_res = D->h2o_far_res;
   const unsigned long long wf_o2 = D->o2_far;
   double bsum_far = 0.0;
@@ -1670,10 +1888,13 @@ k_absorb_win(const AbsorbWinArgs A) {
   {
     LineMasks ln;
     ln.o2_far = wf_o2; ln.h2o_far = wf_both | wf_res; ln.h2o_res = wf_res; ln.h2o_none = 0u; ln.h2o_sd = 0u;
-    double S[NN];
-    h2o_absorb<NFC, true>(M, L, sfn, ln, S, ~(wf_both | wf_res), nullptr, 0.0, &failed_h, &bsum_far);
+    {
+      double Sh[NH];
+      h2o_absorb<NH, true>(M, L, sfn_h, ln, Sh, ~(wf_both | wf_res), nullptr, 0.0, &failed_h, &bsum_far);
 #pragma unroll
-    for (int m = 0; m < NN; ++m) Sh_l[m * nthreads + tid] = S[m];
+      for (int m = 0; m < NH; ++m) Sh_l[m * nthreads + tid] = Sh[m];
+    }
+    double S[NN];
     dry_absorb<NFC, true>(M, L, sfn, ln, S, ~wf_o2, nullptr, &failed_o);
 #pragma unroll
     for (int m = 0; m < NN; ++m) So_l[m * nthreads + tid] = S[m];
@@ -1682,57 +1903,214 @@ k_absorb_win(const AbsorbWinArgs A) {
   const unsigned long long excl_o = wf_o2 & ~failed_o;        // was left out of the node sums: evaluated directly
   // node sums -> a chunk's frequencies: out[j] = sum_m Lt[m][j] S[m]; the matrix is wave-uniform (scalar loads),
   // stored node-major so one node's 16 weights are one contiguous load
-  auto interpolate = [&](const double* S_l, cdoubles Lt, double (&out)[NFC]) {
+  auto interpolate = [&](const double* S_l, cdoubles Lt, int nn, double (&out)[NFC]) {
 #pragma unroll
     for (int j = 0; j < NFC; ++j) out[j] = 0.0;
 #pragma unroll 1
-    for (int m = 0; m < NN; ++m) {                            // one node per trip: 16 scalar weights live at a time
+    for (int m = 0; m < nn; ++m) {                            // one node per trip: 16 scalar weights live at a time
       const double sm = S_l[m * nthreads + tid];
 #pragma unroll
       for (int j = 0; j < NFC; ++j) out[j] = __builtin_fma(Lt[m * NFC + j], sm, out[j]);
     }
   };
 
-  // ---- the window's chunks ----
-  const int nch = D->nchunks;
+  // layer thickness below this level (TAU)
+  bool has_prev = false, neg = false;
+  double dz = 0.0;
+  if constexpr (TAU) {
+    has_prev = active && lev > 0 && lane > 0;
+    const double z0 = A.T.z[prof * A.nlev];
+    dz = has_prev ? ((zi - z0) - (A.T.z[off - 1] - z0)) : 0.0;
+  }
+
+  // ---- the window's chunks (no workgroup barrier inside: the waves drift apart and fill each other's stalls) ----
   for (int c = 0; c < nch; ++c) {
     const int jbase = (D->first_chunk + c) * NFC;
     const int nfc = min(NFC, A.nf - jbase);
-    __syncthreads();                                          // everyone is done with the previous chunk's frequencies
-    if (tid < NFC) {
-      const double f = cfrq[jbase + min(tid, nfc - 1)];
-      sfq[2 * tid] = f; sfq[2 * tid + 1] = f * f;
-      double fdep = 1.0;
-      if (M->n2_fdep) { const double q = f * (1.0 / 450.0); fdep = 0.5 + fdiv(0.5, 1.0 + q * q); }
-      sfq[2 * NFC + 2 + tid] = fdep;
-    }
-    if (tid == WAVE - 1) {
-      double lo = cfrq[jbase], hi = lo;
-      for (int j = 1; j < nfc; ++j) { const double f = cfrq[jbase + j]; lo = fmin(lo, f); hi = fmax(hi, f); }
-      sfq[2 * NFC] = lo; sfq[2 * NFC + 1] = hi;
-    }
-    __syncthreads();
+    fill_chunk_table<NFC>(sfq, M, cfrq, jbase, nfc, lane);
     const cdoubles Lt = Lw + (size_t)c * NN * NFC;            // [node][target] of this chunk
-    const LineMasks lm = line_masks(M, sfq, NFC, lane);
+    const cdoubles Lth = Lwh + (size_t)c * NH * NFC;
+    LineMasks lm;
+    { const cmasks q = CM + (D->first_chunk + c);
+      lm.o2_far = q->o2_far; lm.h2o_far = q->h2o_far; lm.h2o_none = q->h2o_none; lm.h2o_res = q->h2o_res; lm.h2o_sd = q->h2o_sd; }
     // The level state is the same for every chunk, and the compiler would hoist every per-(level, line) quantity
     // of the direct lines out of the chunk loop (hundreds of registers).  Laundering it keeps them inside.
     LevelState Lc = L;
     asm volatile("" : "+v"(Lc.t), "+v"(Lc.p), "+v"(Lc.rho), "+v"(Lc.pdry));
     double init[NFC], awet[NFC], adry[NFC];
-    interpolate(Sh_l, Lt, init);
-    h2o_absorb<NFC>(M, Lc, sfq, lm, awet, excl_h, init, bsum_far);
-    if (active) {
+    if constexpr (!TAU) {
+      interpolate(Sh_l, Lth, NH, init);
+      h2o_absorb<NFC>(M, Lc, sfq, lm, awet, excl_h, init, bsum_far);
+      if (active) {
 #pragma unroll
-      for (int j = 0; j < NFC; ++j)
-        if (j < nfc) A.awet[(prof * A.nf + jbase + j) * A.nlev + tid] = awet[j];
-    }
-    interpolate(So_l, Lt, init);
-    dry_absorb<NFC>(M, Lc, sfq, lm, adry, excl_o, init);
-    if (active) {
+        for (int j = 0; j < NFC; ++j)
+          if (j < nfc) A.awet[(prof * A.nf + jbase + j) * A.nlev + tid] = awet[j];
+      }
+      interpolate(So_l, Lt, NN, init);
+      dry_absorb<NFC>(M, Lc, sfq, lm, adry, excl_o, init);
+      if (active) {
 #pragma unroll
-      for (int j = 0; j < NFC; ++j)
-        if (j < nfc) A.adry[(prof * A.nf + jbase + j) * A.nlev + tid] = adry[j];
+        for (int j = 0; j < NFC; ++j)
+          if (j < nfc) A.adry[(prof * A.nf + jbase + j) * A.nlev + tid] = adry[j];
+      }
+    } else {
+      // Dry first: its line loops are the register-hungry ones (four far lines in flight), so they run with
+      // nothing parked; the 16 dry layer optical depths then sit through the lighter H2O evaluation.
+      interpolate(So_l, Lt, NN, init);
+      dry_absorb<NFC>(M, Lc, sfq, lm, adry, excl_o, init);
+#pragma unroll
+      for (int j = 0; j < NFC; j += 4) {
+#pragma clang fp contract(off)
+        double d4[4] = {adry[j], adry[j + 1], adry[j + 2], adry[j + 3]};
+        const double db[4] = {lane_below(d4[0]), lane_below(d4[1]), lane_below(d4[2]), lane_below(d4[3])};
+        if (!(MWRT_ABLATE & 16)) layer_value4(d4, db, neg, has_prev);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) adry[j + k] = has_prev ? d4[k] * dz : 0.0;   // from here on: the dry layer optical depth
+      }
+      interpolate(Sh_l, Lth, NH, init);
+      h2o_absorb<NFC>(M, Lc, sfq, lm, awet, excl_h, init, bsum_far);
+#pragma unroll
+      for (int j = 0; j < NFC; j += 4) {
+#pragma clang fp contract(off)               // wet * dz + dry * dz rounds as in the fused kernel
+        double w4[4] = {awet[j], awet[j + 1], awet[j + 2], awet[j + 3]};
+        const double wb[4] = {lane_below(w4[0]), lane_below(w4[1]), lane_below(w4[2]), lane_below(w4[3])};
+        if (!(MWRT_ABLATE & 16)) layer_value4(w4, wb, neg, has_prev);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const double twj = has_prev ? w4[k] * dz : 0.0;
+          adry[j + k] = twj + adry[j + k];
+        }
+      }
+      if (active && (lane > 0 || wave == 0) && !((MWRT_ABLATE & 32) && adry[0] != -1.0)) {   // one 128-byte line per lane and chunk
+        double2* row = (double2*)(A.T.tau + (prof * A.nlev + lev) * (int64_t)A.T.fpitch + jbase);
+#pragma unroll
+        for (int j = 0; j < NFC; j += 2) row[j / 2] = double2{adry[j], adry[j + 1]};
+      }
     }
+  }
+  if constexpr (TAU) {
+    if (__syncthreads_or(neg)) {                // pyrtlib raises ValueError here: flag 2, NaN out
+      blank_tau(A.T, prof, A.nlev, D->first_chunk, nch, tid, nthreads);
+      if (tid == 0) A.T.valid[prof] = 2;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// K2 on fine spectral grids: downwelling Planck-space RTE (RTEquation.planck, from_sat = False, + bright [EXT]) from
+// zenith layer optical depths in HBM, tau [nprof][nlev][fpitch] as the TAU absorption kernels write them.
+//
+// LANE = FREQUENCY.  A wave owns 64 consecutive frequencies of one profile and walks the levels serially: each step
+// is one coalesced 512-byte row read (issued PF levels ahead), the Planck function of the level once per frequency,
+// and the NA slant-path recursions in registers (B_a, T_a per elevation).  No LDS traffic in the loop (two
+// broadcast reads of the level's h/kT), no barriers, no work split to recombine; thin or general layer step is voted
+// per (level, elevation) by the wave -- neighbouring frequencies have neighbouring optical depths.
+// Algorithmic traffic: 8 B per (profile, level, frequency) in, 8 B per TB out.
+// ---------------------------------------------------------------------------------------------
+struct RteTauArgs {
+  const ModelFlat* M;
+  const double* tau;       // [nprof][nlev][fpitch]
+  const double* t;         // [nprof][nlev] K
+  const double* frq;       // [nf] GHz
+  const double* airmass;   // [nang]; elevations a0 .. a0 + NA - 1 are this launch's
+  double* tb;              // [nprof][nang][nf]
+  const uint8_t* valid;    // [nprof] as the absorption kernel left it: != 1 -> NaN rows
+  int nlev, nf, nang, fpitch, a0;
+};
+
+constexpr int RTE_THREADS = 256;
+constexpr int RTE_PF = 8;        // levels in flight per lane
+
+template <int NA>
+__global__ void __launch_bounds__(RTE_THREADS)
+k_rte_tau(const RteTauArgs A) {
+  extern __shared__ __attribute__((aligned(16))) double hkl[];    // {h/(k T_i) per GHz, its inverse} per level
+  const int tid = threadIdx.x;
+  const int64_t prof = blockIdx.x;
+  const int nlev = A.nlev, nf = A.nf;
+  const cmodel M = (cmodel)A.M;
+  const cdoubles cam = (cdoubles)A.airmass;
+  const double hk = 1e9 * M->planck_h / M->boltzmann_k;
+  const double inv_hk = 1e-9 * M->boltzmann_k / M->planck_h;
+  for (int l = tid; l < nlev; l += RTE_THREADS) {
+    const double ti = A.t[prof * nlev + l];
+    hkl[2 * l] = fdiv(hk, ti);
+    hkl[2 * l + 1] = ti * inv_hk;
+  }
+  __syncthreads();
+  const int f0 = blockIdx.y * RTE_THREADS + (tid & ~(WAVE - 1));
+  if (f0 >= nf) return;                                           // a wave past the last frequency
+  const int fi = blockIdx.y * RTE_THREADS + tid;
+  const bool live = fi < nf;
+  const int fc = live ? fi : nf - 1;                              // idle lanes shadow the last frequency (votes stay clean)
+  const double qnan = __builtin_nan("");
+  if (A.valid[prof] != 1) {                                       // NaN input / negative absorption: every TB of the profile is NaN
+    if (live) {
+#pragma unroll
+      for (int a = 0; a < NA; ++a) A.tb[(prof * A.nang + A.a0 + a) * nf + fi] = qnan;
+    }
+    return;
+  }
+  const double f = A.frq[fc];
+  const double rf = fdiv(1.0, f);
+  double am[NA], B[NA], T[NA];
+  double am_max = 0.0;                                            // NaN air masses (their rows come out NaN either way) aside
+#pragma unroll
+  for (int a = 0; a < NA; ++a) { am[a] = cam[A.a0 + a]; B[a] = 0.0; T[a] = 1.0; am_max = fmax(am_max, fabs(am[a])); }
+  const double* col = A.tau + prof * nlev * (int64_t)A.fpitch + fc;
+  const int64_t pitch = A.fpitch;
+  double bprev = planck_b(f * hkl[0], rf * hkl[1]);
+  double cur[RTE_PF];
+#pragma unroll
+  for (int k = 0; k < RTE_PF; ++k) cur[k] = col[(int64_t)min(1 + k, nlev - 1) * pitch];
+  for (int i0 = 1; i0 < nlev; i0 += RTE_PF) {
+    double nxt[RTE_PF];
+#pragma unroll
+    for (int k = 0; k < RTE_PF; ++k) nxt[k] = col[(int64_t)min(i0 + RTE_PF + k, nlev - 1) * pitch];
+#pragma unroll
+    for (int k = 0; k < RTE_PF; ++k) {
+      const int i = i0 + k;
+      if (i < nlev) {
+        const double tz = cur[k];
+        const double bi = planck_b(f * hkl[2 * i], rf * hkl[2 * i + 1]);
+        // boflay (1 - E) = (B_{i-1} + B_i E) (1 - E)/(1 + E) = (B_{i-1} + B_i E) tanh(tau/2): the thin-layer step
+        auto thin_step = [&](int a, double tl) {
+          const double E = fexp_small(-tl);
+          const double th = ftanh_half_small(tl);
+          B[a] = __builtin_fma(__builtin_fma(bi, E, bprev) * T[a], th, B[a]);
+          T[a] *= E;
+        };
+        if (__all(!(fabs(tz) * am_max > EXP_SMALL_X))) {          // thin at the longest path: thin at all of them, one vote
+#pragma unroll
+          for (int a = 0; a < NA; ++a) thin_step(a, tz * am[a]);
+        } else {
+#pragma unroll
+          for (int a = 0; a < NA; ++a) {
+            const double tl = tz * am[a];
+            if (__all(!(fabs(tl) > EXP_SMALL_X))) {
+              thin_step(a, tl);
+            } else {
+              const double E = fexp(-tl);
+              const double lay = fdiv1(__builtin_fma(bi, E, bprev), 1.0 + E);
+              B[a] = __builtin_fma(lay * T[a], 1.0 - E, B[a]);
+              T[a] *= E;
+            }
+          }
+        }
+        bprev = bi;
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < RTE_PF; ++k) cur[k] = nxt[k];
+  }
+  if (!live) return;
+  const double hvk = f * hk;
+  const double bbg = fdiv(1.0, fexp(fdiv(hvk, M->t_cosmic)) - 1.0);   // B(T_cosmic, f)
+#pragma unroll
+  for (int a = 0; a < NA; ++a) {
+    // T is exp(-tauprof) of the whole path; pyrtlib's "tauprof < 125" cut is T > exp(-125)
+    const double boftotl = (T[a] > TRANS_MIN) ? __builtin_fma(bbg, T[a], B[a]) : B[a];
+    A.tb[(prof * A.nang + A.a0 + a) * nf + fi] = fdiv(hvk, flog(1.0 + fdiv(1.0, boftotl)));
   }
 }
 

@@ -7,6 +7,9 @@ with NO collective on the data path.  The only exchange is the final gather of t
 ``[nprof][nang][nf]`` result shards -- ``torch.distributed.all_gather`` (backend "nccl" is RCCL on
 ROCm, riding xGMI; "gloo" in the CPU tests).  Payloads are tiny against xGMI (config 4:
 0.98 MB per GPU), so a single un-bucketed call is right; see DESIGN.md section 6.
+
+``GatherRing`` is the repeated form of the same exchange (what ``bench.py`` times): K result batches
+per rank in a ring of slots, gathered to every rank in buckets while later batches are computed.
 """
 from __future__ import annotations
 
@@ -98,3 +101,81 @@ def tb_batch_sharded(model, z, p, t, rh, frq, ang, group=None, device_id: Option
     tb_all = gather_shards(torch.from_numpy(np.ascontiguousarray(tb)).to(dev), nprof, group)
     valid_all = gather_shards(torch.from_numpy(np.ascontiguousarray(valid)).to(dev), nprof, group)
     return tb_all.cpu().numpy(), valid_all.cpu().numpy()
+
+
+class GatherRing:
+    """K result batches per rank, a ring of ``slots`` of them, all-gathered to every rank in buckets.
+
+    ``out`` is this rank's ring ``[slots, ...]``; ``gathered`` ``[world, slots, ...]`` receives every rank's ring.
+    ``run(step, n)`` calls ``step(s)`` for s = 0 .. n-1 (it must write ``out[s % slots]``) and gathers finished
+    slots ``bucket`` at a time; the bucket is cut one step before the end so that the gather left exposed after the
+    last step carries a single batch, and before the ring wraps everything in flight is drained (the slots about to
+    be overwritten must have left).  Every batch is gathered -- none is skipped.
+
+    On GPUs the steps run on ``compute_stream`` and each gather on ``comm_stream`` behind an event, so it overlaps
+    the following steps (RCCL over xGMI: tens of microseconds per ~4-MB bucket).  With both streams ``None`` (CPU
+    tensors, gloo) the same control flow runs without stream handling -- which is how the indexing is tested
+    off-GPU (tests/test_distributed_gloo.py).  ``world == 1`` without a process group: the ring only runs the steps."""
+
+    def __init__(self, out, gathered, bucket: int, group=None, compute_stream=None, comm_stream=None, collective=True):
+        self.out, self.gathered = out, gathered
+        self.slots = int(out.shape[0])
+        self.bucket = max(1, min(self.slots, int(bucket)))
+        self.group = group
+        self.compute_stream, self.comm_stream = compute_stream, comm_stream
+        self.collective = bool(collective)
+        self.works = []
+        self.gathers = 0                     # collectives issued (diagnostic)
+
+    def gather_slots(self, b0: int, b1: int):
+        """all_gather of result slots [b0, b1), behind the steps that wrote them"""
+        import torch
+        import torch.distributed as dist
+        world = self.gathered.shape[0]
+        parts = [self.gathered[r, b0:b1] for r in range(world)]
+        if self.comm_stream is not None:
+            ev = torch.cuda.Event()
+            ev.record(self.compute_stream)
+            self.comm_stream.wait_event(ev)
+            with torch.cuda.stream(self.comm_stream):
+                self.works.append(dist.all_gather(parts, self.out[b0:b1], group=self.group, async_op=True))
+        else:
+            self.works.append(dist.all_gather(parts, self.out[b0:b1], group=self.group, async_op=True))
+        self.gathers += 1
+
+    def drain(self):
+        for w in self.works:
+            w.wait()                         # (GPU: the current stream waits for the collective)
+        self.works.clear()
+        if self.comm_stream is not None:
+            import torch
+            torch.cuda.current_stream().wait_stream(self.comm_stream)
+
+    def run(self, step, n: int, mark_last=None, on_drain=None):
+        """``mark_last``: an event recorded on the compute stream right after the last step, before its gather.
+        ``on_drain(s0, s1)``: called after each drain with the range of steps whose batches are now complete in
+        ``gathered`` on this rank (tests)."""
+        slots, bucket = self.slots, self.bucket
+        pending = 0                          # first slot of the bucket being filled
+        done_from = 0                        # first step not yet reported to on_drain
+        for s in range(n):
+            slot = s % slots
+            if slot == 0 and s > 0:          # ring wrap: the slots about to be overwritten must have left
+                if self.collective:
+                    self.drain()
+                if on_drain is not None:
+                    on_drain(done_from, s)
+                done_from = s
+                pending = 0
+            step(s)
+            if mark_last is not None and s == n - 1:
+                mark_last.record(self.compute_stream)
+            # ... and the bucket is cut one step before the end, so that the only gather left exposed after the
+            # last step carries a single batch
+            if self.collective and (slot + 1 - pending == bucket or slot == slots - 1 or s >= n - 2):
+                self.gather_slots(pending, slot + 1)
+                pending = slot + 1
+        if self.collective:
+            self.drain()
+        if on_drain is not None and n > 0:
+            on_drain(done_from, n)

@@ -73,3 +73,70 @@ def test_two_rank_gloo_matches_single_process(nprof):
         assert np.array_equal(valid, vref)
         assert np.array_equal(np.isnan(tb), np.isnan(ref))
         assert np.array_equal(np.nan_to_num(tb), np.nan_to_num(ref))
+
+
+def _ring_worker(rank, world, port, cases, q):
+    sys.path.insert(0, ROOT)
+    import torch
+    import torch.distributed as dist
+    from mwr_fast_forward_operators_and_lbls_amd.distributed import GatherRing
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    report = []
+    try:
+        for K, slots, bucket in cases:
+            out = torch.full((slots, 3, 2), -1.0, dtype=torch.float64)
+            gathered = torch.full((world, slots, 3, 2), -2.0, dtype=torch.float64)
+            ring = GatherRing(out, gathered, bucket)
+            seen = []
+
+            def step(s):
+                out[s % slots] = float(rank * 1000 + s)          # the batch of (rank, step)
+
+            def on_drain(s0, s1):
+                # every batch of every rank of steps [s0, s1) sits in its slot on THIS rank
+                for s in range(s0, s1):
+                    for r in range(world):
+                        assert bool((gathered[r, s % slots] == float(r * 1000 + s)).all()), (K, slots, bucket, rank, r, s)
+                seen.extend(range(s0, s1))
+
+            ring.run(step, K, on_drain=on_drain)
+            assert seen == list(range(K)), (K, slots, bucket, seen[:5])
+            assert not ring.works
+            report.append((K, slots, bucket, ring.gathers))
+        q.put((rank, report))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_gather_ring_two_rank_gloo():
+    """bench.py's N>1 exchange (distributed.GatherRing, the only implementation it calls) with world_size 2 on CPU:
+    every rank ends up with every batch of every rank in the right slot -- K below, at and beyond the ring length
+    (wrap at `slots`), bucket sizes 1 and 5, the bucket cut one step before the end."""
+    import torch.multiprocessing as mp
+    cases = [(K, 256, b) for K in (1, 2, 5, 20, 300) for b in (1, 5)] + [(7, 4, 3), (9, 4, 1), (8, 4, 5), (600, 256, 5)]
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_ring_worker, args=(r, 2, port, cases, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=300) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert got[0] == got[1] and len(got[0]) == len(cases)
+    for (K, slots, bucket, gathers) in got[0]:
+        assert gathers >= -(-K // max(1, min(slots, bucket)))          # at least ceil(K / bucket) collectives: none skipped
+
+
+def test_gather_ring_single_process_without_collective():
+    """world = 1 without a process group: the ring only runs the steps (bench.py --gpus 1)."""
+    import torch
+    from mwr_fast_forward_operators_and_lbls_amd.distributed import GatherRing
+    out = torch.zeros((4, 2))
+    ring = GatherRing(out, None, 2, collective=False)
+    calls = []
+    ring.run(lambda s: calls.append(s), 11)
+    assert calls == list(range(11)) and ring.gathers == 0

@@ -1141,3 +1141,98 @@ def test_randomised_parity_hunt_short(gpu_ctx, mode):
     r = subprocess.run(cmd, cwd=root, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-1500:])
     assert "fuzz ok" in r.stdout
+
+
+def _layer_tau_pair(gpu_ctx, model, P, frq, ang, mode=0):
+    """mwrt_layer_tau_batch_device -> mwrt_tb_from_layer_tau_device on device buffers; returns (tau, tb, valid)."""
+    import torch
+    dev = torch.device("cuda:0")
+    nprof, nlev = P["z"].shape
+    nf, nang = len(frq), len(ang)
+    pitch = gpu_ctx.layer_tau_pitch(nf)
+    assert pitch % 16 == 0 and nf <= pitch < nf + 16
+    d = {k: torch.from_numpy(np.ascontiguousarray(P[k])).to(dev) for k in ("z", "p", "t", "rh")}
+    tau = torch.full((nprof, nlev, pitch), -7.0, dtype=torch.float64, device=dev)
+    out = torch.full((nprof, nang, nf), -7.0, dtype=torch.float64, device=dev)
+    val = torch.full((nprof,), 9, dtype=torch.uint8, device=dev)
+    st = torch.cuda.Stream()
+    gpu_ctx.set_absorption_mode(mode)
+    try:
+        with torch.cuda.stream(st):
+            gpu_ctx.layer_tau_batch_device(model, nprof, nlev, d["z"].data_ptr(), d["p"].data_ptr(), d["t"].data_ptr(),
+                                           d["rh"].data_ptr(), frq, tau.data_ptr(), pitch, val.data_ptr(), stream=st.cuda_stream)
+            gpu_ctx.tb_from_layer_tau_device(model, nprof, nlev, tau.data_ptr(), pitch, d["t"].data_ptr(), frq, ang,
+                                             val.data_ptr(), out.data_ptr(), stream=st.cuda_stream)
+        st.synchronize()
+    finally:
+        gpu_ctx.set_absorption_mode(0)
+    return tau.cpu().numpy()[:, :, :nf], out.cpu().numpy(), val.cpu().numpy()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", ["fine-windowed", "fine-direct", "hatpro", "ragged-70", "tall-300", "tall-600", "two-levels"])
+def test_layer_tau_two_kernel_form(gpu_ctx, case):
+    """K1 + layer step -> zenith layer optical depth in HBM (8 B per point, frequency fastest) -> k_rte_tau
+    (lane = frequency): the layer optical depths meet the oracle's zenith `taulay` to 1e-9 relative, the TBs meet the
+    oracle to 1e-6 K and the fused kernel to 1e-8 K, for windowed and every-line absorption, level counts on both sides of
+    the wave seams (63 levels per wave + 1 repeated), and elevation counts that need one launch (7, 10) or several (9, 23)."""
+    nlev = {"tall-300": 300, "tall-600": 600, "two-levels": 2}.get(case, 180)
+    P = pr.synthetic_profiles(4, 97, nlev=max(nlev, 24))
+    if nlev == 2:
+        P = {k: v[:, :2].copy() for k, v in P.items()}
+    frq = {"fine-windowed": pr.fine_grid_frequencies(1000)[300:812], "fine-direct": pr.fine_grid_frequencies(1000)[300:812],
+           "hatpro": pr.HATPRO_FRQS, "ragged-70": np.sort(np.random.default_rng(5).uniform(15.0, 200.0, 70))}.get(
+               case, np.linspace(50.0, 58.0, 37))
+    angs = {"fine-windowed": pr.BENCH_ELEVATIONS_7, "fine-direct": pr.REFERENCE_ELEVATIONS,
+            "hatpro": np.linspace(90.0, 4.0, 9), "ragged-70": np.linspace(90.0, 3.0, 23)}.get(case, np.array([90.0, 5.4]))
+    mode = {"fine-windowed": 2, "fine-direct": 1}.get(case, 0)
+    tau, tb, val = _layer_tau_pair(gpu_ctx, "R24", P, frq, angs, mode)
+    assert (val == 1).all() and np.isfinite(tb).all() and (tau[:, 0, :] == 0.0).all()
+    m = sp.get_model("R24")
+    sub = np.arange(0, len(frq), max(1, len(frq) // 12))
+    ref = lo.tb_cloud_rte(m, P["z"][2], P["p"][2], P["t"][2], P["rh"][2], frq[sub], np.concatenate(([90.0], angs)))
+    nang = len(angs)
+    assert np.allclose(tau[2][:, sub].T, ref["taulay"][:, 0, :], rtol=1e-9, atol=1e-300)
+    assert np.abs(tb[2][:, sub] - ref["tbtotal"].reshape(nang + 1, len(sub))[1:]).max() <= TOL_K
+    gpu_ctx.set_absorption_mode(1)
+    try:
+        fused, fv = gpu_ctx.tb_batch("R24", P["z"], P["p"], P["t"], P["rh"], frq, angs)
+    finally:
+        gpu_ctx.set_absorption_mode(0)
+    assert (fv == 1).all() and np.abs(fused - tb).max() <= 1e-8
+
+
+@pytest.mark.gpu
+def test_layer_tau_form_nan_and_negative_absorption(gpu_ctx):
+    """The two-kernel form keeps the NaN rules: a NaN in z / p / T / rh blanks that profile (valid 0), negative
+    absorption flags 2 with NaN TBs (pyrtlib raises), a NaN elevation blanks its own rows only; neighbours untouched.
+    Both through the public pair and through the automatic fine-grid path of mwrt_tb_batch."""
+    import dataclasses
+    frq = pr.fine_grid_frequencies(1000)[:384]
+    ang = np.array([90.0, np.nan, 5.4])
+    P = pr.synthetic_profiles(7, 98)
+    clean_tau, clean_tb, _ = _layer_tau_pair(gpu_ctx, "R17", P, frq, ang)
+    Q = {k: v.copy() for k, v in P.items()}
+    Q["z"][1, 0] = np.nan; Q["p"][2, 179] = np.nan; Q["t"][4, 63] = np.nan; Q["rh"][6, 126] = np.nan
+    for mode in (0, 1):
+        tau, tb, val = _layer_tau_pair(gpu_ctx, "R17", Q, frq, ang, mode)
+        assert val.tolist() == [1, 0, 0, 1, 0, 1, 0]
+        for i in (1, 2, 4, 6):
+            assert np.isnan(tb[i]).all() and np.isnan(tau[i]).all()
+        for i in (0, 3, 5):
+            assert np.isnan(tb[i][1]).all() and not np.isnan(tb[i][[0, 2]]).any()
+            if mode == 0:
+                assert np.array_equal(tb[i][[0, 2]], clean_tb[i][[0, 2]]) and np.array_equal(tau[i], clean_tau[i])
+    auto, av = gpu_ctx.tb_batch("R17", Q["z"], Q["p"], Q["t"], Q["rh"], frq, ang)
+    assert av.tolist() == [1, 0, 0, 1, 0, 1, 0] and np.array_equal(np.nan_to_num(auto), np.nan_to_num(tb_auto_ref(gpu_ctx, Q, frq, ang)))
+    bad = dataclasses.replace(sp.get_model("R98"), name="R98_negcont_tau", h2o_cf=-1e-6)
+    for mode in (0, 1):
+        tau, tb, val = _layer_tau_pair(gpu_ctx, bad, P, frq, np.array([90.0, 19.2]), mode)
+        assert (val == 2).all() and np.isnan(tb).all()
+    tb, val = gpu_ctx.tb_batch(bad, P["z"], P["p"], P["t"], P["rh"], frq, np.array([90.0, 19.2]))
+    assert (val == 2).all() and np.isnan(tb).all()
+
+
+def tb_auto_ref(gpu_ctx, Q, frq, ang):
+    """the public pair in automatic mode: what the automatic fine-grid path of mwrt_tb_batch runs"""
+    return _layer_tau_pair(gpu_ctx, "R17", Q, frq, ang, 0)[1]
