@@ -14,6 +14,44 @@ from typing import Dict, Tuple
 import numpy as np
 
 
+def encode_strings(dims, values, attrs):
+    """A string variable ('U', 'S' or object-of-str) as the classic data model stores it: a char array with a trailing
+    string-length dimension ``string<N>`` and ``_Encoding`` (what xarray's encoder writes for NETCDF4_CLASSIC / NetCDF-3;
+    the reference's Campaign / Location variables, preprocessing4all.py:1219-1220, travel this way through
+    PyRTlib_processing.py:205-211)."""
+    arr = np.asarray(values)
+    if arr.dtype.kind == "S":
+        raw = arr
+    else:
+        raw = np.char.encode(arr.astype("U"), "utf-8")
+    n = max(1, raw.dtype.itemsize)
+    chars = np.frombuffer(np.ascontiguousarray(raw.astype(f"S{n}")).tobytes(), dtype="S1").reshape(arr.shape + (n,))
+    out_attrs = dict(attrs or {})
+    out_attrs.setdefault("_Encoding", "utf-8")
+    return tuple(dims) + (f"string{n}",), chars, out_attrs
+
+
+def decode_char_array(dims, arr, attrs):
+    """Inverse of ``encode_strings`` (xarray's CharacterArrayCoder + EncodedStringCoder): the last dimension of an 'S1'
+    array is the string length; the result is a 'U' array without it."""
+    attrs = dict(attrs or {})
+    enc = attrs.pop("_Encoding", "utf-8")
+    if isinstance(enc, bytes):
+        enc = enc.decode()
+    a = np.ascontiguousarray(arr)
+    if a.ndim == 0:
+        joined = a.reshape(1).view("S1")
+        return tuple(dims), np.char.decode(joined, enc)[0], attrs
+    n = a.shape[-1]
+    joined = a.view(f"S{n}").reshape(a.shape[:-1]) if n > 0 else np.zeros(a.shape[:-1], dtype="S1")
+    return tuple(dims)[:-1], np.char.decode(np.char.rstrip(joined, b"\0"), enc, "replace"), attrs
+
+
+def is_string_array(arr) -> bool:
+    arr = np.asarray(arr)
+    return arr.dtype.kind in "US" or (arr.dtype.kind == "O" and arr.size > 0 and all(isinstance(x, (str, bytes)) for x in arr.ravel()))
+
+
 class Variable:
     def __init__(self, dims: Tuple[str, ...], values, attrs=None):
         self.dims = tuple(dims)
@@ -61,19 +99,24 @@ class Dataset:
     #    produce or read (no netCDF4 / h5py).
     def to_netcdf3(self, path: str):
         from scipy.io import netcdf_file
+        enc = {k: (Variable(*encode_strings(v.dims, v.values, v.attrs)) if is_string_array(v.values) else v)
+               for k, v in self._vars.items()}
         with netcdf_file(path, "w", version=2) as f:
             dims = {}
-            for v in self._vars.values():
+            for v in enc.values():
                 for d, n in zip(v.dims, v.values.shape):
                     if dims.setdefault(d, n) != n:
                         raise ValueError(f"dimension {d} has conflicting lengths")
             for d, n in dims.items():
                 f.createDimension(d, n)
-            for k, v in self._vars.items():
+            for k, v in enc.items():
                 arr = v.values
+                if arr.dtype.kind == "b":
+                    arr = arr.astype(np.int8)
                 if arr.dtype.kind in "iu" and arr.dtype.itemsize > 4:
                     arr = arr.astype(np.float64)         # NetCDF-3 has no 64-bit integers
-                var = f.createVariable(k, arr.dtype.newbyteorder("=").char if arr.dtype.kind != "f" else ("d" if arr.dtype.itemsize == 8 else "f"), v.dims)
+                code = "c" if arr.dtype.kind == "S" else (arr.dtype.newbyteorder("=").char if arr.dtype.kind != "f" else ("d" if arr.dtype.itemsize == 8 else "f"))
+                var = f.createVariable(k, code, v.dims)
                 var[...] = arr
                 for ak, av in v.attrs.items():
                     setattr(var, ak, av)
@@ -88,7 +131,10 @@ class Dataset:
             for k, var in f.variables.items():
                 attrs = {a: (getattr(var, a).decode() if isinstance(getattr(var, a), bytes) else getattr(var, a))
                          for a in var._attributes}
-                ds._vars[k] = Variable(tuple(var.dimensions), np.array(var[...]), attrs)
+                arr, dims = np.array(var[...]), tuple(var.dimensions)
+                if arr.dtype.kind == "S" and arr.dtype.itemsize == 1 and arr.ndim >= 1:
+                    dims, arr, attrs = decode_char_array(dims, arr, attrs)
+                ds._vars[k] = Variable(dims, arr, attrs)
             ds.attrs = {a: (v.decode() if isinstance(v, bytes) else v) for a, v in f._attributes.items()}
         return ds
 

@@ -6,8 +6,12 @@ Where xarray + netCDF4 are installed the wrapper simply uses them.  Where they a
 HDF5 shared library is, this module reads the same files: root-group variables of numeric type, their
 dimensions through the dimension scales netCDF-4 attaches (``DIMENSION_LIST`` object references), numeric and
 string attributes, ``_FillValue`` / ``scale_factor`` / ``add_offset`` decoding as ``xr.open_dataset`` does by
-default.  Chunking, deflate and shuffle are libhdf5's business.  Not read: groups below the root, compound /
-enum / vlen variables, string variables (the hot path's inputs have none: preprocessing4all.py:1195-1233).
+default.  String variables -- the input carries ``Campaign`` and ``Location`` on (time,), preprocessing4all.py:1219-1220,
+which the reference hands through to its output (PyRTlib_processing.py:205-211) and the plot scripts index
+(multi_campaign_plots_and_ana.py:184-196) -- are read whether stored as variable-length strings (NETCDF4) or as char arrays
+with a string-length dimension (NETCDF4_CLASSIC), and written back as the latter.  Chunking, deflate and shuffle are
+libhdf5's business.  Not read (each skipped WITH a warning naming the variable): groups below the root, compound / enum /
+vlen-of-number variables.
 
 Writing follows the netCDF-4 on-disk conventions (one dimension-scale dataset per dimension,
 ``_Netcdf4Dimid``, creation-order tracking, ``_nc3_strict`` for the classic model); it needs libhdf5_hl for
@@ -28,7 +32,9 @@ from typing import Optional
 
 import numpy as np
 
-from .dataset import Dataset, Variable
+import warnings
+
+from .dataset import Dataset, Variable, decode_char_array, encode_strings, is_string_array
 
 HDF5_MAGIC = b"\x89HDF\r\n\x1a\n"
 _HIDDEN = {"DIMENSION_LIST", "REFERENCE_LIST", "CLASS", "NAME", "_Netcdf4Dimid", "_Netcdf4Coordinates",
@@ -314,14 +320,21 @@ def read_netcdf4(path: str, decode: bool = True) -> Dataset:
                     continue                                       # a bare dimension, no data
                 tid, sid = h.H5Dget_type(oid), h.H5Dget_space(oid)
                 dt, shape = _np_dtype(L, tid), _shape(L, sid)
-                h.H5Tclose(tid)
-                h.H5Sclose(sid)
-                if dt is None:
-                    continue
-                arr = np.empty(shape, dtype=dt)
-                if arr.size and h.H5Dread(oid, L.NATIVE[(dt.kind, dt.itemsize)], 0, 0, 0, arr.ctypes.data_as(C.c_void_p)) < 0:
-                    raise OSError(f"{path}: reading variable {nm.value.decode()} failed")
                 name = nm.value.decode()
+                try:
+                    if dt is None and h.H5Tget_class(tid) == 3:
+                        arr = _read_string_dataset(L, oid, tid, sid, shape, path, name)
+                    elif dt is None:
+                        warnings.warn(f"{path}: variable {name} has an HDF5 type this reader does not handle "
+                                      f"(class {h.H5Tget_class(tid)}) -- skipped", RuntimeWarning, stacklevel=2)
+                        continue
+                    else:
+                        arr = np.empty(shape, dtype=dt)
+                        if arr.size and h.H5Dread(oid, L.NATIVE[(dt.kind, dt.itemsize)], 0, 0, 0, arr.ctypes.data_as(C.c_void_p)) < 0:
+                            raise OSError(f"{path}: reading variable {name} failed")
+                finally:
+                    h.H5Tclose(tid)
+                    h.H5Sclose(sid)
                 dims = _dimension_names(L, oid, len(shape))
                 if dims is None:
                     if hidden.get("CLASS") == "DIMENSION_SCALE" and len(shape) == 1:
@@ -329,7 +342,12 @@ def read_netcdf4(path: str, decode: bool = True) -> Dataset:
                     else:
                         dims = [phony.setdefault(n, f"phony_dim_{len(phony)}") for n in shape]
                 attrs = {k: v for k, v in hidden.items() if k not in _HIDDEN}
-                if decode:
+                if arr.dtype.kind == "S" and arr.dtype.itemsize == 1 and arr.ndim >= 1 and decode:
+                    dims, arr, attrs = decode_char_array(dims, arr, attrs)         # char array -> strings, string-length dimension dropped
+                elif arr.dtype.kind == "S" and decode:
+                    arr = np.char.decode(np.char.rstrip(arr, b"\0"), "utf-8", "replace")
+                    attrs.pop("_Encoding", None)
+                elif decode and arr.dtype.kind != "U":
                     arr, attrs = _decode_cf(arr, attrs)
                 ds[name] = Variable(tuple(dims), arr, attrs)
             finally:
@@ -337,6 +355,30 @@ def read_netcdf4(path: str, decode: bool = True) -> Dataset:
     finally:
         h.H5Fclose(fid)
     return ds
+
+
+def _read_string_dataset(L: _Lib, did, tid, sid, shape, path, name):
+    """H5T_STRING dataset -> 'U' array (variable-length strings) or 'S<size>' array (fixed length; size 1 = a char array)."""
+    h = L.h5
+    n = int(np.prod(shape)) if shape else 1
+    if h.H5Tis_variable_str(tid) > 0:
+        mt = h.H5Tcopy(L.C_S1)
+        h.H5Tset_size(mt, C.c_size_t(-1).value)
+        h.H5Tset_cset(mt, h.H5Tget_cset(tid))
+        buf = (C.c_char_p * max(n, 1))()
+        ok = n == 0 or h.H5Dread(did, mt, 0, 0, 0, buf) >= 0
+        vals = [(b or b"").decode("utf-8", "replace") for b in buf][:n] if ok else None
+        if ok and n and L.reclaim:
+            L.reclaim(mt, sid, 0, buf)
+        h.H5Tclose(mt)
+        if vals is None:
+            raise OSError(f"{path}: reading string variable {name} failed")
+        return np.array(vals, dtype="U").reshape(shape) if n else np.zeros(shape, dtype="U1")
+    size = int(h.H5Tget_size(tid))
+    buf = C.create_string_buffer(max(size * n, 1))
+    if n and h.H5Dread(did, tid, 0, 0, 0, buf) < 0:
+        raise OSError(f"{path}: reading string variable {name} failed")
+    return np.frombuffer(buf.raw[:size * n], dtype=f"S{size}").reshape(shape).copy()
 
 
 def _decode_cf(arr, attrs):
@@ -404,6 +446,12 @@ def write_netcdf4(ds: Dataset, path: str, classic: bool = True, deflate: int = 0
         raise ImportError(f"libhdf5_hl (dimension scales) not found next to {L.path}")
     h = L.h5
     dims = {}
+    # string variables travel as char arrays + a string-length dimension (the classic data model has no string type)
+    src = ds
+    ds = Dataset(attrs=src.attrs)
+    for k in src.keys():
+        v = src[k]
+        ds[k] = Variable(*encode_strings(v.dims, v.values, v.attrs)) if is_string_array(v.values) else v
     for k in ds.keys():
         v = ds[k]
         for d, n in zip(v.dims, v.values.shape):
@@ -427,11 +475,11 @@ def write_netcdf4(ds: Dataset, path: str, classic: bool = True, deflate: int = 0
             arr = np.ascontiguousarray(arr)
             if arr.dtype.kind == "b":
                 arr = arr.astype(np.int8)
-            if arr.dtype.kind not in "fiu":
+            if arr.dtype.kind not in "fiu" and arr.dtype != np.dtype("S1"):
                 raise TypeError(f"variable {name}: unsupported dtype {arr.dtype}")
             if classic and arr.dtype.kind in "iu" and arr.dtype.itemsize == 8:
                 arr = arr.astype(np.float64)                       # the classic model has no 64-bit integers
-            mt = L.NATIVE[(arr.dtype.kind, arr.dtype.itemsize)]
+            mt = L.C_S1 if arr.dtype.kind == "S" else L.NATIVE[(arr.dtype.kind, arr.dtype.itemsize)]   # NC_CHAR = 1-byte string
             shape = (hsize_t * max(arr.ndim, 1))(*arr.shape)
             sid = h.H5Screate_simple(arr.ndim, shape, None) if arr.ndim else h.H5Screate(0)
             dcpl = h.H5Pcreate(L.P_DATASET_CREATE)

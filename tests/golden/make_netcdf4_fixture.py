@@ -9,7 +9,10 @@ Needs an interpreter with h5py; in this image that is /opt/conda/bin/python3.9 (
 Layout mirrors what the pre-processing stage hands the LBL wrapper (preprocessing4all.py:1195-1233): four
 ``Level_*`` variables (N_Levels, time, Crop), ``elevation``, an unlimited ``time`` coordinate, chunked +
 shuffled + deflated float data with ``_FillValue``, a packed int16 variable with scale_factor / add_offset, a
-dimension without a coordinate variable, fixed- and variable-length string attributes.  The expected values
+dimension without a coordinate variable, fixed- and variable-length string attributes, and the two string variables
+of the real input on (time,) (preprocessing4all.py:1219-1220): ``Campaign`` as variable-length strings (how the NETCDF4
+format stores them) and ``Location`` as a char array with a ``string8`` dimension and ``_Encoding`` (how NETCDF4_CLASSIC
+stores them).  The expected values
 are regenerated from the same seed by the test (tests/test_netcdf4_io.py).  libnetcdf itself is not in the
 image, so this pins our reader against the HDF5 conventions, not against libnetcdf's writer.
 """
@@ -31,6 +34,7 @@ def content():
     rh[0, 1, 1] = np.nan
     return dict(nlev=nlev, ntime=ntime, ncrop=ncrop, z=z, p=p, t=t, rh=rh,
                 time=np.array([1.7e9, 1.7e9 + 3600, 1.7e9 + 7200]), elevation=np.array([90.0, 30.0, 5.4]),
+                campaign=["FESSTVaL", "Vital I", "S\u00f6g"], location=["RAO", "JOYCE", "X"],
                 packed=np.array([[-32768, 0, 100], [200, -5, 32767]], dtype=np.int16))
 
 
@@ -60,7 +64,7 @@ def main():
                   "time": dim("time", c["ntime"], c["time"], unlimited=True),
                   "Crop": dim("Crop", c["ncrop"], np.arange(c["ncrop"], dtype=np.int32)),
                   "elevation": dim("elevation", 3, c["elevation"]),
-                  "two": dim("two", 2)}
+                  "two": dim("two", 2), "string8": dim("string8", 8)}
         scales["time"].attrs["units"] = "seconds since 1970-01-01"
 
         def var(name, dims, data, **kw):
@@ -80,6 +84,14 @@ def main():
             v.attrs["_FillValue"] = fill
             v.attrs["units"] = units
             v.attrs["long_name"] = np.bytes_(f"{key} on levels")
+        v = var("Campaign", ("time",), np.array(c["campaign"], dtype=object), dtype=h5py.string_dtype("utf-8"))
+        v.attrs["long_name"] = "campaign of the sounding"
+        chars = np.zeros((c["ntime"], 8), dtype="S1")
+        for i, name in enumerate(c["location"]):
+            b = name.encode()
+            chars[i, :len(b)] = np.frombuffer(b, dtype="S1")
+        v = var("Location", ("time", "string8"), chars)
+        v.attrs["_Encoding"] = "utf-8"
         v = var("packed", ("two", "elevation"), c["packed"])
         v.attrs["_FillValue"] = np.int16(-32768)
         v.attrs["scale_factor"] = np.float64(0.01)

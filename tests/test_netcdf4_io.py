@@ -35,7 +35,14 @@ def test_reads_the_h5py_written_fixture():
     assert nio.is_hdf5(FIXTURE)
     ds = nio.read_netcdf4(FIXTURE)
     # creation order, bare dimensions (N_Levels, two) are not variables
-    assert list(ds.keys()) == ["time", "Crop", "elevation", "Level_z", "Level_Pressure", "Level_Temperature", "Level_RH", "packed"]
+    assert list(ds.keys()) == ["time", "Crop", "elevation", "Level_z", "Level_Pressure", "Level_Temperature", "Level_RH",
+                               "Campaign", "Location", "packed"]
+    # the input's string variables (preprocessing4all.py:1219-1220): variable-length strings and a char array alike
+    assert ds["Campaign"].dims == ("time",) and ds["Campaign"].values.tolist() == c["campaign"]
+    assert ds["Campaign"].attrs == {"long_name": "campaign of the sounding"}
+    assert ds["Location"].dims == ("time",) and ds["Location"].values.tolist() == c["location"] and ds["Location"].attrs == {}
+    rawloc = nio.read_netcdf4(FIXTURE, decode=False)["Location"]
+    assert rawloc.dims == ("time", "string8") and rawloc.values.dtype == np.dtype("S1") and rawloc.attrs["_Encoding"] == "utf-8"
     assert ds.attrs == {"title": "netCDF-4 layout written with h5py", "Conventions": "CF-1.8"}
     for name, key in (("Level_z", "z"), ("Level_Pressure", "p"), ("Level_RH", "rh")):
         v = ds[name]
@@ -69,6 +76,8 @@ def sample_output():
     ds["elevation"] = (("elevation",), np.array([90.0, 4.2]))
     ds["count"] = (("time", "Crop"), np.arange(6, dtype=np.int32).reshape(3, 2))
     ds["big"] = (("time",), np.array([2**40, 1, 2], dtype=np.int64))
+    ds["Campaign"] = (("time",), np.array(["FESSTVaL", "Vital I", "S\u00f6g"]))
+    ds["Campaign"].attrs = {"long_name": "campaign"}
     return ds
 
 
@@ -79,7 +88,9 @@ def test_write_then_read_round_trip(tmp_path, deflate):
     nio.write_netcdf4(ds, path, classic=True, deflate=deflate)
     assert nio.is_hdf5(path)
     back = nio.read_netcdf4(path)
-    assert list(back.keys()) == ["time", "elevation", "TBs_PyRTlib_R24", "count", "big"]   # dimensions' coordinates first
+    assert list(back.keys()) == ["time", "elevation", "TBs_PyRTlib_R24", "count", "big", "Campaign"]   # dimensions' coordinates first
+    assert back["Campaign"].dims == ("time",) and back["Campaign"].values.tolist() == ["FESSTVaL", "Vital I", "S\u00f6g"]
+    assert back["Campaign"].attrs == {"long_name": "campaign"}
     assert back.attrs == {"title": "LBL TBs", "n_models": 3 + 1}
     v = back["TBs_PyRTlib_R24"]
     assert v.dims == ("time", "N_Channels", "elevation", "Crop")
@@ -115,11 +126,11 @@ def test_written_file_carries_netcdf4_dimension_scales_for_h5py(tmp_path):
     assert res.returncode == 0, res.stderr
     got = json.loads(res.stdout.strip().splitlines()[-1])
     assert got["scales"] == [["/time"], ["/N_Channels"], ["/elevation"], ["/Crop"]]
-    assert got["is_scale"] == {"time": True, "N_Channels": True, "elevation": True, "Crop": True,
-                               "TBs_PyRTlib_R24": False, "count": False, "big": False}
+    assert got["is_scale"] == {"time": True, "N_Channels": True, "elevation": True, "Crop": True, "string8": True,
+                               "TBs_PyRTlib_R24": False, "count": False, "big": False, "Campaign": False}
     assert got["names"]["time"] == "time" and got["names"]["elevation"] == "elevation"
     assert got["names"]["N_Channels"] == "This is a netCDF dimension but not a netCDF variable.        14"
-    assert sorted(got["dimid"].values()) == [0, 1, 2, 3] and got["dimid"]["time"] == 0
+    assert sorted(got["dimid"].values()) == [0, 1, 2, 3, 4] and got["dimid"]["time"] == 0
     assert got["strict"] == 1 and got["units"] == "K"
     assert got["sum"] == pytest.approx(float(sample_output()["TBs_PyRTlib_R24"].values[0].sum()), rel=1e-14)
 
@@ -140,6 +151,12 @@ def test_wrapper_reads_netcdf4_input_and_writes_netcdf4_output(tmp_path, oracle_
     assert back["TBs_PyRTlib_R24"].dims == ('time', 'N_Channels', 'elevation', 'Crop')
     assert np.array_equal(back["TBs_PyRTlib_R24"].values, tb, equal_nan=True)
     assert back["TBs_PyRTlib_R24"].attrs["units"] == "K"
+    # Campaign / Location ride through the wrapper into the output file (PyRTlib_processing.py:205-211), both formats
+    assert back["Campaign"].values.tolist() == c["campaign"] and back["Location"].values.tolist() == c["location"]
+    path3 = str(tmp_path / "tbs_nc3.nc")
+    pp.write_dataset(out, path3)
+    back3 = pp.open_dataset(path3)
+    assert back3["Campaign"].values.tolist() == c["campaign"] and back3["Location"].dims == ("time",)
     assert pp.parse_arguments(["-i", "a.nc", "-o", "b.nc", "--netcdf4"]).netcdf4 is True
 
 
