@@ -95,8 +95,12 @@ struct mwrt_context {
   ParamCache frq_cache, am_cache, elev_cache;
   // fine-grid absorption: window descriptors + Lagrange matrices per (model, frequency list), immutable like ParamCache
   int absorption_mode = 0;      // 0 auto, 1 direct, 2 windowed
-  struct WinEntry { uint64_t model_id; std::vector<double> frq; char* d_blob; size_t off_lag, off_lagh, off_masks; int nwin; };
+  struct WinEntry { uint64_t model_id; std::vector<double> frq; char* d_blob; size_t off_lag, off_lagh; int nwin; };
   std::vector<WinEntry> win_cache;
+  // line classification of every frequency chunk (LineMasks), per (model, frequency list, chunk width): depends on the
+  // frequencies and the table only, so the host computes it once instead of every workgroup voting on it
+  struct MaskEntry { uint64_t model_id; int nfc; std::vector<double> frq; LineMasks* d_masks; };
+  std::vector<MaskEntry> mask_cache;
   // ray-tracing workspace: path factors [nprof][nang][nlev] and the per-profile ducting flag
   DevBuf d_amf, d_duct;
   // fine-grid two-kernel path: materialised absorption of one profile batch (awet | adry)
@@ -317,6 +321,52 @@ bool windows_eligible(const double* frq, int nf) {
   return true;
 }
 
+// line_masks of every chunk of `nfc` frequencies (what the kernels' line loops are steered by; mwrt_kernels.hip.h LineMasks)
+void chunk_masks(const mwrt_model_desc& t, const double* frq, int nf, int nfc, std::vector<LineMasks>* out) {
+  const int nchunks = (nf + nfc - 1) / nfc;
+  out->assign(nchunks, LineMasks{});
+  for (int ch = 0; ch < nchunks; ++ch) {
+    const int j0 = ch * nfc, j1 = std::min(nf, j0 + nfc);
+    LineMasks& lm = (*out)[ch];
+    for (int k = 0; k < t.n_o2; ++k) {
+      double dmin = 1e300;
+      for (int j = j0; j < j1; ++j) dmin = std::min(dmin, std::fabs(frq[j] - t.o2_f[k]));
+      if (dmin >= FAR_MIN_GHZ + FAR_SHIFT_GHZ) lm.o2_far |= 1ull << k;
+    }
+    for (int k = 0; k < t.n_h2o; ++k) {
+      double dmin = 1e300, smin = 1e300;
+      for (int j = j0; j < j1; ++j) { dmin = std::min(dmin, std::fabs(frq[j] - t.h2o_fl[k])); smin = std::min(smin, std::fabs(frq[j] + t.h2o_fl[k])); }
+      if (dmin >= FAR_H2O_GHZ) lm.h2o_far |= 1u << k;
+      if (dmin >= 750.0 + FAR_H2O_GHZ && smin >= 750.0 + FAR_H2O_GHZ) lm.h2o_none |= 1u << k;
+      if (smin >= 750.0 + FAR_H2O_GHZ) lm.h2o_res |= 1u << k;
+      if (t.h2o_w2[k] > 0.0) lm.h2o_sd |= 1u << k;
+    }
+  }
+}
+
+// device copy of chunk_masks(...), immutable and cached like the window descriptors
+int get_masks(mwrt_context* c, const mwrt_model* m, const double* frq, int nf, int nfc, const LineMasks** out) {
+  for (auto& e : c->mask_cache)
+    if (e.model_id == m->id && e.nfc == nfc && (int)e.frq.size() == nf && std::memcmp(e.frq.data(), frq, sizeof(double) * nf) == 0) {
+      *out = e.d_masks; return MWRT_OK;
+    }
+  if (c->mask_cache.size() >= 64) {                     // bounded: drop the oldest entry behind a device-wide drain
+    HIP_TRY(hipDeviceSynchronize());
+    (void)hipFree(c->mask_cache.front().d_masks);
+    c->mask_cache.erase(c->mask_cache.begin());
+  }
+  std::vector<LineMasks> host;
+  chunk_masks(m->h_desc, frq, nf, nfc, &host);
+  mwrt_context::MaskEntry e{m->id, nfc, std::vector<double>(frq, frq + nf), nullptr};
+  HIP_TRY(hipMalloc((void**)&e.d_masks, sizeof(LineMasks) * host.size()));
+  hipError_t err = hipMemcpyAsync(e.d_masks, host.data(), sizeof(LineMasks) * host.size(), hipMemcpyHostToDevice, c->stream);
+  if (err == hipSuccess) err = hipStreamSynchronize(c->stream);
+  if (err != hipSuccess) { (void)hipFree(e.d_masks); HIP_TRY(err); }
+  c->mask_cache.push_back(std::move(e));
+  *out = c->mask_cache.back().d_masks;
+  return MWRT_OK;
+}
+
 // Chebyshev nodes of [flo, fhi] and the barycentric Lagrange weights of every target frequency of the window,
 // stored [chunk][node][target]; targets past the last frequency repeat it (their results are discarded)
 template <int NNODES>
@@ -356,7 +406,6 @@ double sd_halfwidth_bound(const mwrt_model_desc& t, int k) {
 struct WindowSet {
   std::vector<WinDesc> wins;
   std::vector<double> lag, lag_h;       // [nwin][WIN_CHUNKS][nodes][WIN_NFC]
-  std::vector<LineMasks> masks;         // [nchunks]
 };
 
 void build_windows(const mwrt_model_desc& t, const double* frq, int nf, WindowSet* ws) {
@@ -394,35 +443,16 @@ void build_windows(const mwrt_model_desc& t, const double* frq, int nf, WindowSe
       // anything else (a cutoff crossing the window, or both terms out) is left to the per-chunk loops
     }
   }
-  // line_masks() of every chunk, on the host: the sets depend on the frequencies and the table only
-  ws->masks.assign(nchunks, LineMasks{});
-  for (int ch = 0; ch < nchunks; ++ch) {
-    const int j0 = ch * WIN_NFC, j1 = std::min(nf, j0 + WIN_NFC);
-    LineMasks& lm = ws->masks[ch];
-    for (int k = 0; k < t.n_o2; ++k) {
-      double dmin = 1e300;
-      for (int j = j0; j < j1; ++j) dmin = std::min(dmin, std::fabs(frq[j] - t.o2_f[k]));
-      if (dmin >= FAR_MIN_GHZ + FAR_SHIFT_GHZ) lm.o2_far |= 1ull << k;
-    }
-    for (int k = 0; k < t.n_h2o; ++k) {
-      double dmin = 1e300, smin = 1e300;
-      for (int j = j0; j < j1; ++j) { dmin = std::min(dmin, std::fabs(frq[j] - t.h2o_fl[k])); smin = std::min(smin, std::fabs(frq[j] + t.h2o_fl[k])); }
-      if (dmin >= FAR_H2O_GHZ) lm.h2o_far |= 1u << k;
-      if (dmin >= 750.0 + FAR_H2O_GHZ && smin >= 750.0 + FAR_H2O_GHZ) lm.h2o_none |= 1u << k;
-      if (smin >= 750.0 + FAR_H2O_GHZ) lm.h2o_res |= 1u << k;
-      if (t.h2o_w2[k] > 0.0) lm.h2o_sd |= 1u << k;
-    }
-  }
 }
 
-struct WinPtrs { const WinDesc* win; const double* lag; const double* lag_h; const LineMasks* masks; int nwin; };
+struct WinPtrs { const WinDesc* win; const double* lag; const double* lag_h; const LineMasks* masks; int nwin; };   // masks: get_masks(.., WIN_NFC)
 
 int get_windows(mwrt_context* c, const mwrt_model* m, const double* frq, int nf, WinPtrs* out) {
   for (auto& e : c->win_cache)
     if (e.model_id == m->id && (int)e.frq.size() == nf && std::memcmp(e.frq.data(), frq, sizeof(double) * nf) == 0) {
       *out = WinPtrs{(const WinDesc*)e.d_blob, (const double*)(e.d_blob + e.off_lag), (const double*)(e.d_blob + e.off_lagh),
-                     (const LineMasks*)(e.d_blob + e.off_masks), e.nwin};
-      return MWRT_OK;
+                     nullptr, e.nwin};
+      return get_masks(c, m, frq, nf, WIN_NFC, &out->masks);
     }
   if (c->win_cache.size() >= 16) {                      // bounded: drop the oldest entry behind a device-wide drain
     HIP_TRY(hipDeviceSynchronize());
@@ -432,16 +462,14 @@ int get_windows(mwrt_context* c, const mwrt_model* m, const double* frq, int nf,
   WindowSet ws;
   build_windows(m->h_desc, frq, nf, &ws);
   auto up = [](size_t x) { return (x + 255) & ~(size_t)255; };
-  mwrt_context::WinEntry e{m->id, std::vector<double>(frq, frq + nf), nullptr, 0, 0, 0, (int)ws.wins.size()};
+  mwrt_context::WinEntry e{m->id, std::vector<double>(frq, frq + nf), nullptr, 0, 0, (int)ws.wins.size()};
   e.off_lag = up(sizeof(WinDesc) * ws.wins.size());
   e.off_lagh = e.off_lag + up(sizeof(double) * ws.lag.size());
-  e.off_masks = e.off_lagh + up(sizeof(double) * ws.lag_h.size());
-  const size_t total = e.off_masks + up(sizeof(LineMasks) * ws.masks.size());
+  const size_t total = e.off_lagh + up(sizeof(double) * ws.lag_h.size());
   std::vector<char> host(total, 0);
   std::memcpy(host.data(), ws.wins.data(), sizeof(WinDesc) * ws.wins.size());
   std::memcpy(host.data() + e.off_lag, ws.lag.data(), sizeof(double) * ws.lag.size());
   std::memcpy(host.data() + e.off_lagh, ws.lag_h.data(), sizeof(double) * ws.lag_h.size());
-  std::memcpy(host.data() + e.off_masks, ws.masks.data(), sizeof(LineMasks) * ws.masks.size());
   HIP_TRY(hipMalloc((void**)&e.d_blob, total));
   hipError_t err = hipMemcpyAsync(e.d_blob, host.data(), total, hipMemcpyHostToDevice, c->stream);
   if (err == hipSuccess) err = hipStreamSynchronize(c->stream);
@@ -449,8 +477,8 @@ int get_windows(mwrt_context* c, const mwrt_model* m, const double* frq, int nf,
   c->win_cache.push_back(std::move(e));
   const auto& k = c->win_cache.back();
   *out = WinPtrs{(const WinDesc*)k.d_blob, (const double*)(k.d_blob + k.off_lag), (const double*)(k.d_blob + k.off_lagh),
-                 (const LineMasks*)(k.d_blob + k.off_masks), k.nwin};
-  return MWRT_OK;
+                 nullptr, k.nwin};
+  return get_masks(c, m, frq, nf, WIN_NFC, &out->masks);
 }
 
 // plane-parallel air mass 1 / sin(elev) per elevation (NaN elevation -> NaN air mass: that angle's rows come out NaN)
@@ -506,6 +534,7 @@ int layer_tau_launch(mwrt_context* c, const mwrt_model* m, int64_t nprof, int nl
   }
   AbsorbArgs a{};
   a.M = m->d_desc; a.p = d_p; a.t = d_t; a.rh = d_rh; a.frq = dev_frq; a.nlev = nlev; a.nf = nf; a.T = T;
+  { int rc = get_masks(c, m, frq, nf, TAU_NFC, &a.masks); if (rc) return rc; }
   timing_begin(c, st);
   hipError_t e = launch_absorb_tau(a, dim3((unsigned)nprof, (unsigned)((nf + TAU_NFC - 1) / TAU_NFC)), dim3(threads), st);
   timing_end(c, st);
@@ -580,6 +609,8 @@ int mwrt_destroy(mwrt_context* c) {
   (void)hipStreamSynchronize(c->stream);
   for (auto& e : c->win_cache) (void)hipFree(e.d_blob);
   c->win_cache.clear();
+  for (auto& e : c->mask_cache) (void)hipFree(e.d_masks);
+  c->mask_cache.clear();
   c->frq_cache.release(); c->am_cache.release(); c->elev_cache.release(); c->d_amf.release(); c->d_duct.release(); c->d_alpha.release();
   c->d_in.release(); c->d_out.release();
   c->d_valid.release(); c->d_ex.release();
@@ -636,6 +667,11 @@ int mwrt_model_destroy(mwrt_context* c, mwrt_model* m) {
       if (c->win_cache[i].model_id == m->id) {
         (void)hipFree(c->win_cache[i].d_blob);
         c->win_cache.erase(c->win_cache.begin() + (long)i);
+      }
+    for (size_t i = c->mask_cache.size(); i-- > 0;)
+      if (c->mask_cache[i].model_id == m->id) {
+        (void)hipFree(c->mask_cache[i].d_masks);
+        c->mask_cache.erase(c->mask_cache.begin() + (long)i);
       }
   }
   if (m->d_desc) (void)hipFree(m->d_desc);
@@ -761,7 +797,10 @@ static int tb_launch(mwrt_context* c, int nmodels, const mwrt_model* const* ms, 
       return workspace_release(c, st);
     }
   }
-  rc = launch_fused(c, pick_nfc_fused(c, nlev, nf, nang), a, rows, st, variant);
+  const int nfc_main = pick_nfc_fused(c, nlev, nf, nang);
+  if (variant != FUSED_FROM_ALPHA)
+    for (int i = 0; i < nmodels; ++i) { rc = get_masks(c, ms[i], frq, nf, nfc_main, &a.masks[i]); if (rc) return rc; }
+  rc = launch_fused(c, nfc_main, a, rows, st, variant);
   if (rc == MWRT_OK && rays) rc = workspace_release(c, st);
   return rc;
 }
@@ -939,6 +978,7 @@ int mwrt_absorption_batch_device(mwrt_context* c, const mwrt_model* m, int64_t n
   AbsorbArgs a{};
   a.M = m->d_desc; a.p = d_p; a.t = d_t; a.rh = d_rh; a.frq = dev_frq;
   a.awet = d_awet; a.adry = d_adry; a.nlev = nlev; a.nf = nf;
+  rc = get_masks(c, m, frq, nf, pick_nfc(nf), &a.masks); if (rc) return rc;
   return launch_absorb(c, pick_nfc(nf), a, nprof, st);
 }
 

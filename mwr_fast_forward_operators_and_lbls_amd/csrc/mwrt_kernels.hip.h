@@ -235,8 +235,7 @@ constexpr double FAR_MIN_GHZ = 0.2;
 constexpr double FAR_SHIFT_GHZ = 0.05;     // O2: |dnu| allowance, checked per line by wave vote
 constexpr double FAR_H2O_GHZ = 5.0;        // H2O: covers any pressure shift (< 1 GHz) with margin
 
-// Wave-uniform bit sets over line indices, identical in every wave of the workgroup: lane k tests
-// line k of the table against the chunk's frequencies, one ballot per set.  They steer the line
+// Wave-uniform bit sets over line indices (line k of the table against the chunk's frequencies).  They steer the line
 // loops: each loop walks ONE set with ONE loop body, so the NFC accumulators never cross a
 // control-flow join between differently allocated variants (the v_mov copies that cost).
 struct LineMasks {
@@ -247,31 +246,14 @@ struct LineMasks {
   unsigned h2o_sd;             // speed-dependent lines (W2 > 0)
 };
 
-template <class ModelPtr>
-__device__ __forceinline__ LineMasks line_masks(ModelPtr M, const double* sfq, int nslots, int lane) {
-  bool far_o = false, far_h = false, none_h = false, res_h = false, sd_h = false;
-  const int n_o2 = M->n_o2, n_h2o = M->n_h2o;
-  if (lane < n_o2) {
-    const double c = M->o2_f[lane];
-    double dmin = 1e300;
-    for (int j = 0; j < nslots; ++j) dmin = fmin(dmin, fabs(sfq[2 * j] - c));
-    far_o = dmin >= FAR_MIN_GHZ + FAR_SHIFT_GHZ;
-  }
-  if (lane < n_h2o) {
-    const double c = M->h2o_fl[lane];
-    double dmin = 1e300, smin = 1e300;
-    for (int j = 0; j < nslots; ++j) { const double f = sfq[2 * j]; dmin = fmin(dmin, fabs(f - c)); smin = fmin(smin, fabs(f + c)); }
-    far_h = dmin >= FAR_H2O_GHZ;
-    none_h = dmin >= 750.0 + FAR_H2O_GHZ && smin >= 750.0 + FAR_H2O_GHZ;
-    res_h = smin >= 750.0 + FAR_H2O_GHZ;
-    sd_h = M->h2o_w2[lane] > 0.0;
-  }
+// The sets depend on the chunk's frequencies and the table only: the host computes them once per (model, frequency
+// list, chunk width) -- csrc/mwrt.hip chunk_masks() -- and the kernels fetch their chunk's record through the scalar
+// cache (round 2 had every workgroup derive them: ~180 VALU per lane and chunk).
+typedef const __attribute__((address_space(4))) LineMasks* cmasks;
+__device__ __forceinline__ LineMasks load_masks(const LineMasks* table, int chunk) {
+  const cmasks q = (cmasks)table + chunk;
   LineMasks lm;
-  lm.o2_far = __ballot(far_o);
-  lm.h2o_far = (unsigned)__ballot(far_h);
-  lm.h2o_none = (unsigned)__ballot(none_h);
-  lm.h2o_res = (unsigned)__ballot(res_h);
-  lm.h2o_sd = (unsigned)__ballot(sd_h);
+  lm.o2_far = q->o2_far; lm.h2o_far = q->h2o_far; lm.h2o_none = q->h2o_none; lm.h2o_res = q->h2o_res; lm.h2o_sd = q->h2o_sd;
   return lm;
 }
 
@@ -1163,6 +1145,7 @@ struct FusedArgs {
   double* tauliq; double* tauice;               // optional [nprof][nang][nf]
   // ALPHA instantiation (RTE from materialised absorption): awet, adry [nprof][nf][nlev] as k_absorb writes them
   const double* awet_in; const double* adry_in;
+  const LineMasks* masks[MAX_MULTI];   // per model: LineMasks of every frequency chunk (host-computed)
 };
 
 // NaN / negative-absorption exit: every output of this (profile, chunk) becomes NaN
@@ -1292,7 +1275,7 @@ k_tb_fused(const FusedArgs A) {
   if constexpr (!ALPHA) {
     const double e = goff_gratch_e(ti, rhi);
     const LevelState L = level_state(pi, ti, e);
-    const LineMasks lm = line_masks(M, sfq, NFC, lane);
+    const LineMasks lm = load_masks(A.masks[mi], blockIdx.y);
     h2o_absorb<NFC>(M, L, sfq, lm, awet);
     dry_absorb<NFC>(M, L, sfq, lm, adry);
   }
@@ -1713,6 +1696,7 @@ struct AbsorbArgs {
   double* awet; double* adry;
   int nlev, nf;
   TauOut T;                // TAU instantiations only
+  const LineMasks* masks;  // [nchunks]
 };
 
 template <int NFC, int MAXT, bool TAU = false>
@@ -1745,7 +1729,7 @@ k_absorb(const AbsorbArgs A) {
   double awet[NFC], adry[NFC];
   const double e = goff_gratch_e(ti, rhi);
   const LevelState L = level_state(pi, ti, e);
-  const LineMasks lm = line_masks(M, sfq, NFC, lane);
+  const LineMasks lm = load_masks(A.masks, blockIdx.y);
   h2o_absorb<NFC>(M, L, sfq, lm, awet);
   dry_absorb<NFC>(M, L, sfq, lm, adry);
   if constexpr (!TAU) {
@@ -1854,8 +1838,6 @@ k_absorb_win(const AbsorbWinArgs A) {
   const cwin D = (cwin)(A.win + blockIdx.y);
   const cdoubles Lw = (cdoubles)(A.lagrange + (size_t)blockIdx.y * WIN_CHUNKS * NFC * NN);
   const cdoubles Lwh = (cdoubles)(A.lagrange_h + (size_t)blockIdx.y * WIN_CHUNKS * NFC * NH);
-  typedef const __attribute__((address_space(4))) LineMasks* cmasks;
-  const cmasks CM = (cmasks)A.masks;
   __shared__ double sfn[3 * NFC + 2];                        // the nodes, laid out like a chunk
   __shared__ double sfn_h[3 * NH + 2];                       // the H2O nodes
   __shared__ double sfq_w[MAXT / WAVE][3 * NFC + 2];         // the current chunk, one copy per wave (fill_chunk_table)
@@ -1945,9 +1927,7 @@ k_absorb_win(const AbsorbWinArgs A) {
     fill_chunk_table<NFC>(sfq, M, cfrq, jbase, nfc, lane);
     const cdoubles Lt = Lw + (size_t)c * NN * NFC;            // [node][target] of this chunk
     const cdoubles Lth = Lwh + (size_t)c * NH * NFC;
-    LineMasks lm;
-    { const cmasks q = CM + (D->first_chunk + c);
-      lm.o2_far = q->o2_far; lm.h2o_far = q->h2o_far; lm.h2o_none = q->h2o_none; lm.h2o_res = q->h2o_res; lm.h2o_sd = q->h2o_sd; }
+    const LineMasks lm = load_masks(A.masks, D->first_chunk + c);
     // The level state is the same for every chunk, and the compiler would hoist every per-(level, line) quantity
     // of the direct lines out of the chunk loop (hundreds of registers).  Laundering it keeps them inside.
     LevelState Lc = L;
