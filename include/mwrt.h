@@ -69,6 +69,7 @@ extern "C" {
 #define MWRT_VERSION 300          /* 0.3.0: layer-optical-depth two-kernel form (mwrt_layer_tau_*, mwrt_tb_from_layer_tau_device) */
 #define MWRT_MAX_H2O_LINES 32
 #define MWRT_MAX_O2_LINES 64
+#define MWRT_MAX_X_LINES 64       /* lines of the extra trace species (ozone) */
 #define MWRT_MAX_LEVELS 1024      /* one lane per level, one workgroup per profile */
 #define MWRT_MAX_ANGLES 64
 #define MWRT_STREAM_LEGACY ((void*)(intptr_t)-1)   /* `stream` value meaning hipStream_t 0 */
@@ -109,6 +110,21 @@ typedef struct mwrt_model_desc {
   double o2_w300[MWRT_MAX_O2_LINES], o2_y0[MWRT_MAX_O2_LINES], o2_y1[MWRT_MAX_O2_LINES];
   double o2_g0[MWRT_MAX_O2_LINES], o2_g1[MWRT_MAX_O2_LINES];
   double o2_dnu0[MWRT_MAX_O2_LINES], o2_dnu1[MWRT_MAX_O2_LINES];
+  /* Extra trace species (ozone): pyrtlib's TbCloudRTE(..., o3n=...) adds O3AbsModel.o3_absorption to the dry
+   * absorption [EXT; Rosenkranz o3abs].  The reference builds an O3 profile for the sibling model
+   * (python_src/proc/ARMS_gb_processing.py:94-99) and leaves o3n at None on the LBL path, so this is opt-in
+   * (mwrt_tb_options.o3n) and DATA-FREE here: the line list could not be restated offline; n_x = 0 means "no table"
+   * and a call that passes o3n is refused.  tools/export_pyrtlib_tables.py dumps pyrtlib's list into these fields.
+   *   alpha_x [Np/km] = x_coef * n [molecules m-3] * qvinv * ti^2.5 * sum_k S1_k exp(B_k (1 - ti)) (f/FL_k)^2
+   *                     * [ w_k / ((f - FL_k)^2 + w_k^2) + w_k / ((f + FL_k)^2 + w_k^2) ],
+   *   ti = x_reft / T,  qvinv = 1 - exp(-x_qvib_t / T)  (1 if x_qvib_t <= 0),
+   *   w_k = 0.5346 wc + sqrt(0.2166 wc^2 + 0.6931 bd^2)   (Voigt half width, Olivero & Longbothum 1977),
+   *   wc = W_k p ti^X_k  (p total, hPa),  bd = 4.3e-7 sqrt(T / x_mass) FL_k  (Doppler 1/e half width). */
+  int32_t n_x;
+  int32_t x_reserved;
+  double x_reft, x_qvib_t, x_mass, x_coef;
+  double x_fl[MWRT_MAX_X_LINES], x_s1[MWRT_MAX_X_LINES], x_b[MWRT_MAX_X_LINES];
+  double x_w[MWRT_MAX_X_LINES], x_x[MWRT_MAX_X_LINES];
 } mwrt_model_desc;
 
 /* Optional by-products of execute() (the other DataFrame columns pyrtlib returns; the
@@ -130,6 +146,7 @@ typedef struct mwrt_tb_extras {
  *                    the upstream producer stores kg/kg: python_src/preproc/derive_cloud_water.py:68-142,
  *                    preprocessing4all.py:811-812, :1199-1200 ("Level_Liquid", "Level_Ice").
  *                    RTEquation.cloudy_absorption + exponential_integration(zeroflg = False).
+ *   o3n              ozone number density profiles (see mwrt_model_desc.n_x): opt-in, and refused without a line table.
  *   ray_tracing      != 0: spherical refracted slant paths (RTEquation.refractivity, Thayer 1974, and
  *                    RTEquation.ray_tracing, TBMODEL RAYTRAC) instead of dz / sin(elev) -- matters for the
  *                    4.2 ... 8.4 degree elevations of PyRTlib_processing.py:37.
@@ -139,6 +156,8 @@ typedef struct mwrt_tb_options {
   const double* denice;
   int32_t ray_tracing;
   int32_t reserved0;
+  const double* o3n;       /* ozone number density [nprof][nlev], molecules m-3 (pyrtlib's o3n), or NULL; needs a model
+                              with n_x > 0 (else MWRT_ERR_UNSUPPORTED); added to the dry absorption of every level */
 } mwrt_tb_options;
 
 typedef struct mwrt_context mwrt_context;   /* one per (host thread, GPU): device, stream, workspace */

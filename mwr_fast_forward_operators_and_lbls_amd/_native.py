@@ -39,7 +39,7 @@ class MwrtTbExtras(ctypes.Structure):
 class MwrtTbOptions(ctypes.Structure):
     """include/mwrt.h mwrt_tb_options: the opt-in physics (cloud liquid / ice, ray tracing)."""
     _fields_ = [("denliq", ctypes.c_void_p), ("denice", ctypes.c_void_p), ("ray_tracing", ctypes.c_int32),
-                ("reserved0", ctypes.c_int32)]
+                ("reserved0", ctypes.c_int32), ("o3n", ctypes.c_void_p)]
 
 
 MWRT_VERSION = 300
@@ -244,11 +244,12 @@ class Context:
 
     # -- host-buffer entry points ------------------------------------------------------------
     @_serialised
-    def tb_batch(self, model, z, p, t, rh, frq, elev, extras=False, denliq=None, denice=None, ray_tracing=False):
+    def tb_batch(self, model, z, p, t, rh, frq, elev, extras=False, denliq=None, denice=None, ray_tracing=False, o3n=None):
         """[nprof][nlev] profiles (ground->top) -> tb [nprof][nang][nf], valid [nprof] (+ extras dict).
 
-        ``denliq`` / ``denice`` ([nprof][nlev], g m-3) and ``ray_tracing`` are the opt-in physics of
-        ``mwrt_tb_options``; left at their defaults the call is the reference's clear-sky plane-parallel path."""
+        ``denliq`` / ``denice`` ([nprof][nlev], g m-3), ``ray_tracing`` and ``o3n`` ([nprof][nlev], molecules m-3; the
+        model must carry an extra-species line table) are the opt-in physics of ``mwrt_tb_options``; left at their
+        defaults the call is the reference's clear-sky plane-parallel path."""
         z = _f64(z)
         if z.ndim != 2:
             raise ValueError("profiles must be [nprof][nlev]")
@@ -265,11 +266,12 @@ class Context:
             exs = MwrtTbExtras(*[ex[k].ctypes.data for k in ("tbatm", "tmr", "tauwet", "taudry", "taulay", "tauliq",
                                                               "tauice")])
         opts = None
-        if denliq is not None or denice is not None or ray_tracing:
+        if denliq is not None or denice is not None or ray_tracing or o3n is not None:
             dl = None if denliq is None else _f64(denliq, z.shape, "denliq")
             di = None if denice is None else _f64(denice, z.shape, "denice")
+            do3 = None if o3n is None else _f64(o3n, z.shape, "o3n")
             opts = MwrtTbOptions(dl.ctypes.data if dl is not None else None, di.ctypes.data if di is not None else None,
-                                 int(bool(ray_tracing)), 0)
+                                 int(bool(ray_tracing)), 0, do3.ctypes.data if do3 is not None else None)
         self._check(self._lib.mwrt_tb_batch_opt(
             self._handle, self.model(model), nprof, nlev, _ptr(z), _ptr(p), _ptr(t), _ptr(rh),
             nf, _ptr(frq), nang, _ptr(elev), _ptr(tb), _ptr(valid),
@@ -321,9 +323,9 @@ class Context:
     @_serialised
     def tb_batch_device(self, model, nprof, nlev, d_z, d_p, d_t, d_rh, frq, elev, d_tb, d_valid,
                         extras: Optional[MwrtTbExtras] = None, stream=None, d_denliq=None, d_denice=None,
-                        ray_tracing=False):
+                        ray_tracing=False, d_o3n=None):
         frq, elev = _f64(frq).ravel(), _f64(elev).ravel()
-        if d_denliq is None and d_denice is None and not ray_tracing:
+        if d_denliq is None and d_denice is None and not ray_tracing and d_o3n is None:
             self._check(self._lib.mwrt_tb_batch_device(
                 self._handle, self.model(model), int(nprof), int(nlev), _ptr(d_z), _ptr(d_p), _ptr(d_t), _ptr(d_rh),
                 frq.size, _ptr(frq), elev.size, _ptr(elev), _ptr(d_tb), _ptr(d_valid),
@@ -331,7 +333,8 @@ class Context:
                 _stream(stream)), "mwrt_tb_batch_device")
             return
         opts = MwrtTbOptions(int(d_denliq) if d_denliq is not None else None,
-                             int(d_denice) if d_denice is not None else None, int(bool(ray_tracing)), 0)
+                             int(d_denice) if d_denice is not None else None, int(bool(ray_tracing)), 0,
+                             int(d_o3n) if d_o3n is not None else None)
         self._check(self._lib.mwrt_tb_batch_opt_device(
             self._handle, self.model(model), int(nprof), int(nlev), _ptr(d_z), _ptr(d_p), _ptr(d_t), _ptr(d_rh),
             frq.size, _ptr(frq), elev.size, _ptr(elev), _ptr(d_tb), _ptr(d_valid),

@@ -627,6 +627,7 @@ int mwrt_model_create(mwrt_context* c, const mwrt_model_desc* desc, mwrt_model**
   *out = nullptr;
   if (desc->n_h2o < 0 || desc->n_h2o > MWRT_MAX_H2O_LINES || desc->n_o2 < 0 || desc->n_o2 > MWRT_MAX_O2_LINES)
     return fail(MWRT_ERR_INVALID_ARGUMENT, "line counts out of range");
+  if (desc->n_x < 0 || desc->n_x > MWRT_MAX_X_LINES) return fail(MWRT_ERR_INVALID_ARGUMENT, "extra-species line count out of range");
   HIP_TRY(hipSetDevice(c->device));
   mwrt_model* m = new (std::nothrow) mwrt_model();
   if (!m) return fail(MWRT_ERR_OUT_OF_MEMORY, "host allocation failed");
@@ -688,7 +689,12 @@ static int tb_launch(mwrt_context* c, int nmodels, const mwrt_model* const* ms, 
   if (nmodels < 1 || nmodels > MAX_MULTI || !ms) return fail(MWRT_ERR_INVALID_ARGUMENT, "nmodels must be 1..8");
   const bool cloudy = opt && (opt->denliq || opt->denice);
   const bool rays = opt && opt->ray_tracing != 0;
-  const bool use_opt = cloudy || rays;
+  const bool ozone = opt && opt->o3n;
+  const bool use_opt = cloudy || rays || ozone;
+  if (ozone)
+    for (int i = 0; i < nmodels; ++i)
+      if (ms[i] && ms[i]->h_desc.n_x <= 0)
+        return fail(MWRT_ERR_UNSUPPORTED, "o3n given but the model carries no extra-species line table (mwrt_model_desc.n_x = 0)");
   for (int i = 0; i < nmodels; ++i) {
     int rc = check_common(c, ms[i], nprof, nlev, nf);
     if (rc) return rc;
@@ -739,6 +745,7 @@ static int tb_launch(mwrt_context* c, int nmodels, const mwrt_model* const* ms, 
   // (clear sky: the kernel writes the cloud columns itself -- 0 x air mass for good rows, NaN for blanked profiles
   // and NaN elevations, like every other column)
   if (cloudy) { a.denliq = opt->denliq; a.denice = opt->denice; }
+  if (ozone) a.o3n = opt->o3n;
   if (rays) {
     // RTEquation.refractivity + ray_tracing [EXT] as a pre-kernel on the same stream: path factor ds/dz per
     // (profile, angle, layer) into the context's workspace (grown only, never shrunk)
@@ -891,8 +898,8 @@ int mwrt_tb_batch_opt(mwrt_context* c, const mwrt_model* m, int64_t nprof, int32
   hipStream_t st = c->stream;
   const size_t nin = (size_t)nprof * nlev, nout = (size_t)nprof * nang * nf;
   const size_t nlay = (size_t)nprof * nf * nlev;
-  const bool has_liq = opt && opt->denliq, has_ice = opt && opt->denice;
-  HIP_TRY(c->d_in.reserve((4 + (has_liq ? 1 : 0) + (has_ice ? 1 : 0)) * nin * sizeof(double)));
+  const bool has_liq = opt && opt->denliq, has_ice = opt && opt->denice, has_o3 = opt && opt->o3n;
+  HIP_TRY(c->d_in.reserve((4 + (has_liq ? 1 : 0) + (has_ice ? 1 : 0) + (has_o3 ? 1 : 0)) * nin * sizeof(double)));
   HIP_TRY(c->d_out.reserve(nout * sizeof(double)));
   HIP_TRY(c->d_valid.reserve((size_t)nprof));
   double* din = c->d_in.as<double>();
@@ -903,7 +910,8 @@ int mwrt_tb_batch_opt(mwrt_context* c, const mwrt_model* m, int64_t nprof, int32
   if (opt) {
     double* q = din + 4 * nin;
     if (has_liq) { HIP_TRY(hipMemcpyAsync(q, opt->denliq, nin * sizeof(double), hipMemcpyHostToDevice, st)); dopt.denliq = q; q += nin; }
-    if (has_ice) { HIP_TRY(hipMemcpyAsync(q, opt->denice, nin * sizeof(double), hipMemcpyHostToDevice, st)); dopt.denice = q; }
+    if (has_ice) { HIP_TRY(hipMemcpyAsync(q, opt->denice, nin * sizeof(double), hipMemcpyHostToDevice, st)); dopt.denice = q; q += nin; }
+    if (has_o3) { HIP_TRY(hipMemcpyAsync(q, opt->o3n, nin * sizeof(double), hipMemcpyHostToDevice, st)); dopt.o3n = q; }
     dopt.ray_tracing = opt->ray_tracing;
   }
   constexpr int NEX = 7;                               // tbatm tmr tauwet taudry taulay tauliq tauice

@@ -1016,6 +1016,44 @@ __device__ __forceinline__ double thayer_refindex(double p, double tk, double e)
   return 1.0 + (dryn + wetn) * 1e-06;
 }
 
+// O3AbsModel.o3_absorption [EXT, recalled from Rosenkranz's o3abs -- unverified; the line list is data, include/mwrt.h
+// mwrt_model_desc.n_x]: the extra trace species joins the DRY absorption of this level for the chunk's frequencies
+// (RTEquation.clearsky_absorption(..., o3n) [EXT]).  Generic Van Vleck-Weisskopf lines with a Voigt half width; one
+// reciprocal per line and frequency.  Opt-in path, not tuned.
+template <int NFC>
+__device__ __forceinline__ void x_absorb(cmodel M, double tk, double p, double numden, const double* sfq, double (&adry)[NFC]) {
+  const double ti = fdiv(M->x_reft, tk);
+  const double tiln = flog(ti);
+  const double qvinv = (M->x_qvib_t > 0.0) ? 1.0 - fexp(-fdiv(M->x_qvib_t, tk)) : 1.0;
+  const double sq = 4.3e-07 * fsqrt(fdiv(tk, M->x_mass));
+  double sum[NFC];
+#pragma unroll
+  for (int j = 0; j < NFC; ++j) sum[j] = 0.0;
+  const int nx = M->n_x;
+  for (int k = 0; k < nx; ++k) {
+    const double fl = M->x_fl[k];
+    const double wc = M->x_w[k] * p * fexp(M->x_x[k] * tiln);
+    const double bd = sq * fl;
+    const double w = 0.5346 * wc + fsqrt(__builtin_fma(0.2166 * wc, wc, 0.6931 * (bd * bd)));
+    const double wsq = w * w;
+    const double sw = (M->x_s1[k] * fexp(M->x_b[k] * (1.0 - ti))) * fdiv(w, fl * fl);     // the f^2 of (f/FL)^2 is applied at the end
+    LDS_RELOAD_FENCE();
+#pragma unroll
+    for (int j = 0; j < NFC; ++j) {
+      const double f = sfq[2 * j];
+      const double d1 = f - fl, d2 = f + fl;
+      const double D1 = __builtin_fma(d1, d1, wsq), D2 = __builtin_fma(d2, d2, wsq);
+      const double den12 = D1 * D2;
+      double r = __builtin_amdgcn_rcp(den12);
+      r = __builtin_fma(r, __builtin_fma(-den12, r, 1.0), r);
+      sum[j] = __builtin_fma((D1 + D2) * r, sw, sum[j]);
+    }
+  }
+  const double pref = ((M->x_coef * numden) * qvinv) * fexp(2.5 * tiln);
+#pragma unroll
+  for (int j = 0; j < NFC; ++j) adry[j] = __builtin_fma(pref * sfq[2 * j + 1], sum[j], adry[j]);
+}
+
 // RTEquation.ray_tracing [EXT] (TBMODEL RAYTRAC: Dutton, Thayer & Westwater after Bean & Dutton fig. 3.20).
 // Stores the PATH FACTOR ds_i / dz_i per layer, amf [nprof][nang][nlev] (entry 0 = 0): the slant-path
 // integration multiplies the zenith layer optical depth by it, exactly where the plane-parallel path
@@ -1146,6 +1184,7 @@ struct FusedArgs {
   // ALPHA instantiation (RTE from materialised absorption): awet, adry [nprof][nf][nlev] as k_absorb writes them
   const double* awet_in; const double* adry_in;
   const LineMasks* masks[MAX_MULTI];   // per model: LineMasks of every frequency chunk (host-computed)
+  const double* o3n;       // OPT: ozone number density [nprof][nlev] molecules m-3, or null
 };
 
 // NaN / negative-absorption exit: every output of this (profile, chunk) becomes NaN
@@ -1258,11 +1297,12 @@ k_tb_fused(const FusedArgs A) {
     }
     if (active && bad) atomicOr(&s_flag, 1);
   }
-  double denl = 0.0, deni = 0.0;
+  double denl = 0.0, deni = 0.0, o3n = 0.0;
   if constexpr (OPT) {
     if (A.denliq) denl = A.denliq[off];
     if (A.denice) deni = A.denice[off];
-    if (active && (isnan(denl) || isnan(deni))) atomicOr(&s_flag, 1);
+    if (A.o3n) o3n = A.o3n[off];
+    if (active && (isnan(denl) || isnan(deni) || isnan(o3n))) atomicOr(&s_flag, 1);
   }
   __syncthreads();
   if (s_flag) {                               // check_for_nans: outputs stay NaN, valid = 0
@@ -1278,6 +1318,9 @@ k_tb_fused(const FusedArgs A) {
     const LineMasks lm = load_masks(A.masks[mi], blockIdx.y);
     h2o_absorb<NFC>(M, L, sfq, lm, awet);
     dry_absorb<NFC>(M, L, sfq, lm, adry);
+    if constexpr (OPT) {
+      if (A.o3n) x_absorb<NFC>(M, ti, pi, o3n, sfq, adry);       // clearsky_absorption(..., o3n): ozone joins the dry term
+    }
   }
   // neighbour level i-1: lane-1 through the crossbar, wave seams through a 2*NFC-double edge row
   if (lane == WAVE - 1) {

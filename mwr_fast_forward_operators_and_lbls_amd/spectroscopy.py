@@ -43,6 +43,7 @@ import numpy as np
 
 MAX_H2O_LINES = 32
 MAX_O2_LINES = 64
+MAX_X_LINES = 64
 
 # H2O shift handling (h2o_shift_mode)
 SHIFT_NONE = 0       # R98: no pressure shift of line centres
@@ -98,6 +99,14 @@ class ModelTables:
     t_cosmic: float = 2.736
     planck_h: float = 6.6260755e-34
     boltzmann_k: float = 1.380658e-23
+    # ---- extra trace species (ozone), opt-in and DATA-FREE: pyrtlib's O3 line list could not be restated offline.
+    #      None = no table (a call that passes o3n is refused); tools/export_pyrtlib_tables.py fills it from an
+    #      installed pyrtlib, ModelTables.with_extra_lines() from any source.  Keys: fl s1 b w x (include/mwrt.h). ----
+    xlines: Optional[Dict[str, np.ndarray]] = None
+    x_reft: float = 296.0        # reference temperature of the list
+    x_qvib_t: float = 1008.0     # vibrational partition: qvinv = 1 - exp(-x_qvib_t / T)  (O3 nu2 = 701 cm-1)
+    x_mass: float = 48.0         # molar mass for the Doppler width
+    x_coef: float = 1.0e-10 / 3.14159265358979   # S1 in cm^2 Hz, n in molecules m-3 -> Np/km
     # ---- provenance (host-side only; not part of mwrt_model_desc) ----
     alias_of: Optional[str] = None   # set when this NAME is served by another model's tables
     parity: str = "unpinned"         # "unpinned": restated from the literature; "exported": dumped from an
@@ -106,6 +115,7 @@ class ModelTables:
     H2O_KEYS = ("fl", "s1", "b2", "w0", "x", "w0s", "xs", "sh", "xh", "shs", "xhs",
                 "aair", "aself", "w2", "xw2", "w2s", "xw2s", "d2", "d2s")
     O2_KEYS = ("f", "s300", "be", "w300", "y0", "y1", "g0", "g1", "dnu0", "dnu1")
+    X_KEYS = ("fl", "s1", "b", "w", "x")
 
     def __post_init__(self):
         n = len(self.h2o["fl"])
@@ -116,6 +126,11 @@ class ModelTables:
             self.o2[k] = _a(self.o2[k], m)
         if n > MAX_H2O_LINES or m > MAX_O2_LINES:
             raise ValueError("too many lines for mwrt_model_desc")
+        if self.xlines is not None:
+            nx = len(self.xlines["fl"])
+            self.xlines = {k: _a(self.xlines[k], nx) for k in self.X_KEYS}
+            if nx > MAX_X_LINES:
+                raise ValueError("too many extra-species lines for mwrt_model_desc")
 
     @property
     def n_h2o(self) -> int:
@@ -125,11 +140,24 @@ class ModelTables:
     def n_o2(self) -> int:
         return len(self.o2["f"])
 
+    @property
+    def n_x(self) -> int:
+        return 0 if self.xlines is None else len(self.xlines["fl"])
+
+    def with_extra_lines(self, xlines, name=None, **scalars) -> "ModelTables":
+        """A copy of this record carrying an extra-species (ozone) line table: ``xlines`` = dict of fl [GHz], s1, b,
+        w [GHz/hPa], x; ``scalars`` may override x_reft / x_qvib_t / x_mass / x_coef."""
+        return dataclasses.replace(self, name=name or self.name, alias_of=None if name else self.alias_of,
+                                   h2o={k: np.array(v) for k, v in self.h2o.items()},
+                                   o2={k: np.array(v) for k, v in self.o2.items()},
+                                   xlines={k: np.asarray(xlines[k], dtype=np.float64) for k in self.X_KEYS}, **scalars)
+
     # -- (de)serialisation: JSON is the exchange format with tools/export_pyrtlib_tables.py
     def to_json(self) -> str:
         d = dataclasses.asdict(self)
         d["h2o"] = {k: v.tolist() for k, v in self.h2o.items()}
         d["o2"] = {k: v.tolist() for k, v in self.o2.items()}
+        d["xlines"] = None if self.xlines is None else {k: v.tolist() for k, v in self.xlines.items()}
         return json.dumps(d, indent=1)
 
     @classmethod
@@ -156,6 +184,13 @@ class ModelTables:
             arr = getattr(c, "o2_" + k)
             for i, v in enumerate(self.o2[k]):
                 arr[i] = v
+        c.n_x = self.n_x
+        c.x_reft, c.x_qvib_t, c.x_mass, c.x_coef = self.x_reft, self.x_qvib_t, self.x_mass, self.x_coef
+        if self.xlines is not None:
+            for k in self.X_KEYS:
+                arr = getattr(c, "x_" + k)
+                for i, v in enumerate(self.xlines[k]):
+                    arr[i] = v
         return c
 
 
@@ -174,6 +209,9 @@ class MwrtModelDesc(ctypes.Structure):
             "t_cosmic", "planck_h", "boltzmann_k")]
         + [("h2o_" + k, ctypes.c_double * MAX_H2O_LINES) for k in ModelTables.H2O_KEYS]
         + [("o2_" + k, ctypes.c_double * MAX_O2_LINES) for k in ModelTables.O2_KEYS]
+        + [("n_x", ctypes.c_int32), ("x_reserved", ctypes.c_int32)]
+        + [(k, ctypes.c_double) for k in ("x_reft", "x_qvib_t", "x_mass", "x_coef")]
+        + [("x_" + k, ctypes.c_double * MAX_X_LINES) for k in ModelTables.X_KEYS]
     )
 
 
@@ -529,6 +567,13 @@ def get_model(name: str) -> ModelTables:
                       f"(install real tables with tools/export_pyrtlib_tables.py + register_model)",
                       UserWarning, stacklevel=2)
     return m
+
+
+def number_density_from_ppmv(ppmv, p_hpa, t_k):
+    """Volume mixing ratio [ppmv] -> number density [molecules m-3] (pyrtlib's ``o3n`` unit): n = x p / (k T).
+    The reference's sibling model takes its O3 profile in ppmv (ARMS_gb_processing.py:94-99)."""
+    return np.asarray(ppmv, dtype=np.float64) * 1e-6 * np.asarray(p_hpa, dtype=np.float64) * 100.0 / (
+        1.380649e-23 * np.asarray(t_k, dtype=np.float64))
 
 
 def register_model(tables: ModelTables, overwrite: bool = False):

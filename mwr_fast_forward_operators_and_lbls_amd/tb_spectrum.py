@@ -106,9 +106,19 @@ class TbCloudRTE(object):
         if self._satellite:
             raise NotImplementedError("upwelling (satellite=True) is outside the hot path; the reference "
                                       "sets rte.satellite = False (PyRTlib_processing.py:125)")
+        o3n = None
         if self.o3n is not None:
-            raise NotImplementedError("ozone profile (o3n) is outside the hot path: the O3 line list could not be "
-                                      "restated offline")
+            # pyrtlib: o3n = ozone number density [molecules m-3] per level; O3AbsModel joins the dry absorption.  The
+            # mechanism is here (include/mwrt.h mwrt_model_desc.n_x), the line list is not: it could not be restated
+            # offline, so a model without one still refuses (tools/export_pyrtlib_tables.py --o3 +
+            # spectroscopy.register_model / ModelTables.with_extra_lines install one).
+            if self._tables.n_x == 0:
+                raise NotImplementedError(f"ozone profile (o3n): model {self._absmdl!r} carries no O3 line table -- the list "
+                                          "could not be restated offline; register one (ModelTables.with_extra_lines)")
+            o3n = np.asarray(self.o3n, dtype=np.float64)
+            if o3n.shape != self.z.shape:
+                raise ValueError("o3n must have one value per level")
+            o3n = o3n[None, :]
         denliq = denice = None
         if self.cloudy:
             if self.denliq is None:
@@ -118,7 +128,7 @@ class TbCloudRTE(object):
         z, p, t, rh = (np.ascontiguousarray(a, dtype=np.float64)[None, :] for a in (self.z, self.p, self.tk, self.rh))
         tb, valid, ex = _native.default_context().tb_batch(self._tables, z, p, t, rh, self.frq, self.angles, extras=True,
                                                            denliq=denliq, denice=denice,
-                                                           ray_tracing=bool(self.ray_tracing))
+                                                           ray_tracing=bool(self.ray_tracing), o3n=o3n)
         if valid[0] == 2:
             # pyrtlib raises inside RTEquation.exponential_integration on negative absorption
             raise ValueError("Error encountered in exponential_integration")

@@ -27,6 +27,7 @@ def load():
         _lib.lbl_tables_size.restype = ctypes.c_size_t
         _lib.lbl_tb_profile.restype = ctypes.c_int
         _lib.lbl_tb_profile_opt.restype = ctypes.c_int
+        _lib.lbl_tb_profile_o3.restype = ctypes.c_int
         _lib.lbl_tb_batch.restype = ctypes.c_int
     return _lib
 
@@ -56,8 +57,8 @@ def tb_profile(tables, z, p, t, rh, frq, ang):
     return out
 
 
-def tb_profile_opt(tables, z, p, t, rh, frq, ang, denliq=None, denice=None, ray_tracing=False):
-    """One profile with the opt-in physics (cloud liquid / ice, spherical refracted ray tracing)."""
+def tb_profile_opt(tables, z, p, t, rh, frq, ang, denliq=None, denice=None, ray_tracing=False, o3n=None):
+    """One profile with the opt-in physics (cloud liquid / ice, spherical refracted ray tracing, ozone)."""
     lib = load()
     c = _tables_bytes(tables)
     z, p, t, rh, frq, ang = (np.ascontiguousarray(a, dtype=np.float64) for a in (z, p, t, rh, frq, ang))
@@ -66,8 +67,13 @@ def tb_profile_opt(tables, z, p, t, rh, frq, ang, denliq=None, denice=None, ray_
     n = len(frq) * len(ang)
     keys = ("tbtotal", "tbatm", "tmr", "tauwet", "taudry", "tauliq", "tauice")
     out = {k: np.empty(n) for k in keys}
-    rc = lib.lbl_tb_profile_opt(ctypes.byref(c), len(z), _p(z), _p(p), _p(t), _p(rh), len(frq), _p(frq), len(ang), _p(ang),
-                                _p(dl), _p(di), int(bool(ray_tracing)), *[_p(out[k]) for k in keys])
+    if o3n is not None:
+        o3 = np.ascontiguousarray(o3n, dtype=np.float64)
+        rc = lib.lbl_tb_profile_o3(ctypes.byref(c), len(z), _p(z), _p(p), _p(t), _p(rh), len(frq), _p(frq), len(ang), _p(ang),
+                                   _p(dl), _p(di), int(bool(ray_tracing)), _p(o3), *[_p(out[k]) for k in keys])
+    else:
+        rc = lib.lbl_tb_profile_opt(ctypes.byref(c), len(z), _p(z), _p(p), _p(t), _p(rh), len(frq), _p(frq), len(ang), _p(ang),
+                                    _p(dl), _p(di), int(bool(ray_tracing)), *[_p(out[k]) for k in keys])
     if rc == 2:
         raise ValueError("Error encountered in exponential_integration")
     if rc == 3:

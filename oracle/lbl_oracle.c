@@ -26,6 +26,7 @@
 
 #define LBL_MAX_H2O 32
 #define LBL_MAX_O2 64
+#define LBL_MAX_X 64
 
 /* Same field order as the product's mwrt_model_desc so a test can hand over the same bytes;
  * declared independently on purpose (oracle/ includes nothing from the product). */
@@ -41,6 +42,10 @@ typedef struct lbl_tables {
       h2o_xw2[LBL_MAX_H2O], h2o_w2s[LBL_MAX_H2O], h2o_xw2s[LBL_MAX_H2O], h2o_d2[LBL_MAX_H2O], h2o_d2s[LBL_MAX_H2O];
   double o2_f[LBL_MAX_O2], o2_s300[LBL_MAX_O2], o2_be[LBL_MAX_O2], o2_w300[LBL_MAX_O2], o2_y0[LBL_MAX_O2],
       o2_y1[LBL_MAX_O2], o2_g0[LBL_MAX_O2], o2_g1[LBL_MAX_O2], o2_dnu0[LBL_MAX_O2], o2_dnu1[LBL_MAX_O2];
+  /* extra trace species (ozone) -- opt-in, data supplied by the caller */
+  int32_t n_x, x_reserved;
+  double x_reft, x_qvib_t, x_mass, x_coef;
+  double x_fl[LBL_MAX_X], x_s1[LBL_MAX_X], x_b[LBL_MAX_X], x_w[LBL_MAX_X], x_x[LBL_MAX_X];
 } lbl_tables;
 
 size_t lbl_tables_size(void) { return sizeof(lbl_tables); }
@@ -314,6 +319,26 @@ static int raytrace(int nl, const double* z, const double* n, double angle, doub
   return 0;
 }
 
+
+/* O3AbsModel.o3_absorption [EXT, recalled from Rosenkranz's o3abs -- UNVERIFIED; the line list is data the caller
+ * supplies]: Np/km at one level for number density o3n [molecules m-3]. */
+static double o3_abs(const lbl_tables* m, double tk, double p, double frq, double o3n) {
+  const double ti = m->x_reft / tk;
+  const double qvinv = m->x_qvib_t > 0 ? 1.0 - exp(-m->x_qvib_t / tk) : 1.0;
+  double sum = 0.0;
+  for (int k = 0; k < m->n_x; ++k) {
+    double widthc = m->x_w[k] * p * pow(ti, m->x_x[k]);
+    double betad = 4.3e-07 * sqrt(tk / m->x_mass) * m->x_fl[k];
+    double width = 0.5346 * widthc + sqrt(0.2166 * widthc * widthc + 0.6931 * betad * betad);
+    double s = m->x_s1[k] * exp(m->x_b[k] * (1.0 - ti));
+    double df1 = frq - m->x_fl[k], df2 = frq + m->x_fl[k];
+    double shape = width / (df1 * df1 + width * width) + width / (df2 * df2 + width * width);
+    double r = frq / m->x_fl[k];
+    sum = sum + s * shape * (r * r);
+  }
+  return m->x_coef * o3n * qvinv * pow(ti, 2.5) * sum;
+}
+
 /*
  * TbCloudRTE(z,p,t,rh,frq,angles) + init_absmdl + satellite=False + execute() for ONE profile
  * (PyRTlib_processing.py:123-126).  Outputs [nang][nf] each (pyrtlib DataFrame row order).
@@ -322,13 +347,14 @@ static int raytrace(int nl, const double* z, const double* n, double angle, doub
  * Returns 0 ok, 1 NaN input (outputs NaN), 2 negative absorption (pyrtlib raises ValueError), 3 ducting.
  * A NaN elevation blanks its own rows only (the wrapper's per-k check, :106, :117).
  */
-int lbl_tb_profile_opt(const lbl_tables* m, int nl, const double* z, const double* p, const double* tk, const double* rh,
-                       int nf, const double* frq, int nang, const double* ang,
-                       const double* denliq, const double* denice, int ray_tracing,
-                       double* tbtotal, double* tbatm, double* tmr, double* tauwet, double* taudry,
-                       double* tauliq, double* tauice) {
+static int tb_profile_core(const lbl_tables* m, int nl, const double* z, const double* p, const double* tk, const double* rh,
+                           int nf, const double* frq, int nang, const double* ang,
+                           const double* denliq, const double* denice, int ray_tracing, const double* o3n,
+                           double* tbtotal, double* tbatm, double* tmr, double* tauwet, double* taudry,
+                           double* tauliq, double* tauice) {
   const int nout = nf * nang;
   int bad = 0, allnan = 1;
+  if (o3n) for (int i = 0; i < nl; ++i) bad |= isnan(o3n[i]);
   for (int i = 0; i < nl; ++i) bad |= isnan(z[i]) || isnan(p[i]) || isnan(tk[i]) || isnan(rh[i]);
   if (denliq) for (int i = 0; i < nl; ++i) bad |= isnan(denliq[i]);
   if (denice) for (int i = 0; i < nl; ++i) bad |= isnan(denice[i]);
@@ -372,7 +398,10 @@ int lbl_tb_profile_opt(const lbl_tables* m, int nl, const double* z, const doubl
       for (int i = 1; i < nl; ++i) ds[i] = (zz[i] - zz[i - 1]) * amass;
     }
     for (int j = 0; j < nf; ++j) {
-      for (int i = 0; i < nl; ++i) clearsky_abs(m, p[i], tk[i], e[i], frq[j], &awet[i], &adry[i]);
+      for (int i = 0; i < nl; ++i) {
+        clearsky_abs(m, p[i], tk[i], e[i], frq[j], &awet[i], &adry[i]);
+        if (o3n) adry[i] = adry[i] + o3_abs(m, tk[i], p[i], frq[j], o3n[i]);    /* clearsky_absorption(..., o3n) [EXT] */
+      }
       double sw, sd, sl = 0.0, si = 0.0;
       if (expint(1, awet, ds, nl, pw, &sw) || expint(1, adry, ds, nl, pd, &sd)) { rc = 2; break; }
       if (cloudy) {
@@ -424,6 +453,25 @@ int lbl_tb_profile_opt(const lbl_tables* m, int nl, const double* z, const doubl
     if (tauice) for (int o = 0; o < nout; ++o) tauice[o] = NAN;
   }
   return rc;
+}
+
+int lbl_tb_profile_opt(const lbl_tables* m, int nl, const double* z, const double* p, const double* tk, const double* rh,
+                       int nf, const double* frq, int nang, const double* ang,
+                       const double* denliq, const double* denice, int ray_tracing,
+                       double* tbtotal, double* tbatm, double* tmr, double* tauwet, double* taudry,
+                       double* tauliq, double* tauice) {
+  return tb_profile_core(m, nl, z, p, tk, rh, nf, frq, nang, ang, denliq, denice, ray_tracing, NULL, tbtotal, tbatm, tmr,
+                         tauwet, taudry, tauliq, tauice);
+}
+
+/* ... with an ozone number-density profile o3n [molecules m-3] (TbCloudRTE(..., o3n=...)); needs m->n_x > 0 */
+int lbl_tb_profile_o3(const lbl_tables* m, int nl, const double* z, const double* p, const double* tk, const double* rh,
+                      int nf, const double* frq, int nang, const double* ang,
+                      const double* denliq, const double* denice, int ray_tracing, const double* o3n,
+                      double* tbtotal, double* tbatm, double* tmr, double* tauwet, double* taudry,
+                      double* tauliq, double* tauice) {
+  return tb_profile_core(m, nl, z, p, tk, rh, nf, frq, nang, ang, denliq, denice, ray_tracing, o3n, tbtotal, tbatm, tmr,
+                         tauwet, taudry, tauliq, tauice);
 }
 
 int lbl_tb_profile(const lbl_tables* m, int nl, const double* z, const double* p, const double* tk, const double* rh,

@@ -205,10 +205,37 @@ def o2_absorption(m, pdrykpa, vx, ekpa, frq):
     return npp, ncpp
 
 
-def clearsky_absorption(m, p, tk, e, frq):
+def o3_absorption(m, tk, p, frq, o3n):
+    """O3AbsModel.o3_absorption [EXT, recalled from Rosenkranz's o3abs -- UNVERIFIED; the line list itself is not
+    restated: ``m.xlines`` must come from tools/export_pyrtlib_tables.py or the caller].  pyrtlib adds it to the dry
+    absorption when ``TbCloudRTE(..., o3n=...)`` is given (the reference leaves o3n at None on this path and builds an
+    O3 profile only for the sibling model, ARMS_gb_processing.py:94-99).
+
+    tk [K], p [hPa] (total), o3n [molecules m-3] per level, frq scalar [GHz] -> Np/km per level."""
+    tk = np.asarray(tk, dtype=np.float64)
+    p = np.asarray(p, dtype=np.float64)
+    o3n = np.asarray(o3n, dtype=np.float64)
+    L = m.xlines
+    ti = m.x_reft / tk
+    qvinv = 1.0 - np.exp(-m.x_qvib_t / tk) if m.x_qvib_t > 0 else np.ones_like(tk)
+    summ = np.zeros_like(tk)
+    for k in range(len(L["fl"])):
+        widthc = L["w"][k] * p * ti ** L["x"][k]
+        betad = 4.3e-07 * np.sqrt(tk / m.x_mass) * L["fl"][k]
+        width = 0.5346 * widthc + np.sqrt(0.2166 * widthc * widthc + 0.6931 * betad * betad)
+        s = L["s1"][k] * np.exp(L["b"][k] * (1.0 - ti))
+        df1 = frq - L["fl"][k]
+        df2 = frq + L["fl"][k]
+        shape = width / (df1 * df1 + width * width) + width / (df2 * df2 + width * width)
+        summ = summ + s * shape * (frq / L["fl"][k]) ** 2
+    return m.x_coef * o3n * qvinv * ti ** 2.5 * summ
+
+
+def clearsky_absorption(m, p, tk, e, frq, o3n=None):
     """RTEquation.clearsky_absorption [EXT]; reached from execute(), PyRTlib_processing.py:126.
 
-    p [hPa], tk [K], e [hPa] per level, frq scalar [GHz] -> awet, adry [Np/km] per level."""
+    p [hPa], tk [K], e [hPa] per level, frq scalar [GHz] -> awet, adry [Np/km] per level.
+    ``o3n`` [molecules m-3 per level]: ozone joins the dry absorption (opt-in; needs ``m.xlines``)."""
     p = np.asarray(p, dtype=np.float64)
     tk = np.asarray(tk, dtype=np.float64)
     e = np.asarray(e, dtype=np.float64)
@@ -223,6 +250,8 @@ def clearsky_absorption(m, p, tk, e, frq):
     ao2 = (factor * (npp + ncpp)) * db2np
     an2 = 0.0 if m.n2_ptot else n2_absorption(m, tk, pdrykpa * 10.0, frq)
     adry = ao2 + an2
+    if o3n is not None:
+        adry = adry + o3_absorption(m, tk, p, frq, o3n)
     return awet, adry
 
 
@@ -416,13 +445,14 @@ def bright(hvk, boft):
     return hvk / np.log(1.0 + (1.0 / boft))
 
 
-def tb_cloud_rte(m, z, p, t, rh, frq, angles, denliq=None, denice=None, ray_tracing_on=False):
+def tb_cloud_rte(m, z, p, t, rh, frq, angles, denliq=None, denice=None, ray_tracing_on=False, o3n=None):
     """``TbCloudRTE(z,p,t,rh,frq,angles)`` + ``init_absmdl`` + ``satellite=False`` + ``execute()``
     (PyRTlib_processing.py:123-126): downwelling; clear sky and plane-parallel unless asked otherwise.
 
     z [km] ascending, p [hPa], t [K], rh [0-1] (ground -> top), frq [GHz], angles = ELEVATION [deg].
     Opt-in physics the reference leaves at pyrtlib's defaults: ``denliq`` / ``denice``
-    [g m-3 per level] = ``cloudy=True`` + ``init_cloudy``; ``ray_tracing_on`` = ``ray_tracing=True``.
+    [g m-3 per level] = ``cloudy=True`` + ``init_cloudy``; ``ray_tracing_on`` = ``ray_tracing=True``;
+    ``o3n`` [molecules m-3 per level] = ``TbCloudRTE(..., o3n=...)``.
     Returns a dict of flat arrays ordered like pyrtlib's DataFrame (angle-major, frequency-minor).
     """
     z = np.array(z, dtype=np.float64)
@@ -448,7 +478,7 @@ def tb_cloud_rte(m, z, p, t, rh, frq, angles, denliq=None, denice=None, ray_trac
             amass = 1 / np.sin(angles[k] * np.pi / 180)
             ds = np.append([0], np.diff(z)) * amass
         for j in range(nf):
-            awet, adry = clearsky_absorption(m, p, tk, e, frq[j])
+            awet, adry = clearsky_absorption(m, p, tk, e, frq[j], o3n)
             sw, pw = exponential_integration(True, awet, ds, 0, nl, 1)
             sd, pd_ = exponential_integration(True, adry, ds, 0, nl, 1)
             if cloudy:

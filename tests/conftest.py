@@ -35,14 +35,14 @@ class OracleContext:
     numbers from the oracle.  Installed by the ``oracle_ctx`` fixture through monkeypatching
     ``_native.default_context`` -- the product code itself has no alternative engine."""
 
-    def tb_batch(self, model, z, p, t, rh, frq, elev, extras=False, denliq=None, denice=None, ray_tracing=False):
+    def tb_batch(self, model, z, p, t, rh, frq, elev, extras=False, denliq=None, denice=None, ray_tracing=False, o3n=None):
         import numpy as np
         from mwr_fast_forward_operators_and_lbls_amd import spectroscopy
         tables = spectroscopy.get_model(model) if isinstance(model, str) else model
         tb, valid, ex = oracle_engine(tables, np.ascontiguousarray(z, dtype=float), np.ascontiguousarray(p, dtype=float),
                                       np.ascontiguousarray(t, dtype=float), np.ascontiguousarray(rh, dtype=float),
                                       np.asarray(frq, dtype=float).ravel(), np.asarray(elev, dtype=float).ravel(),
-                                      denliq=denliq, denice=denice, ray_tracing=ray_tracing)
+                                      denliq=denliq, denice=denice, ray_tracing=ray_tracing, o3n=o3n)
         return (tb, valid, ex) if extras else (tb, valid)
 
     def tb_batch_multi(self, models, z, p, t, rh, frq, elev):
@@ -59,7 +59,7 @@ def oracle_ctx(monkeypatch):
     return ctx
 
 
-def oracle_engine(tables, z, p, t, rh, frq, ang, denliq=None, denice=None, ray_tracing=False):
+def oracle_engine(tables, z, p, t, rh, frq, ang, denliq=None, denice=None, ray_tracing=False, o3n=None):
     """The oracle behind the batch signature (profiles [nprof][nlev] -> tb, valid, extras)."""
     import numpy as np
     from oracle import lbl_oracle
@@ -76,13 +76,14 @@ def oracle_engine(tables, z, p, t, rh, frq, ang, denliq=None, denice=None, ray_t
     for i in range(nprof):
         dl = None if denliq is None else np.asarray(denliq, dtype=float)[i]
         di = None if denice is None else np.asarray(denice, dtype=float)[i]
+        o3 = None if o3n is None else np.asarray(o3n, dtype=float)[i]
         if bad_global or any(np.isnan(a[i]).any() for a in (z, p, t, rh)) or \
-                any(x is not None and np.isnan(x).any() for x in (dl, di)):
+                any(x is not None and np.isnan(x).any() for x in (dl, di, o3)):
             valid[i] = 0
             continue
         try:
             r = lbl_oracle.tb_cloud_rte(tables, z[i], p[i], t[i], rh[i], frq, ang[good], denliq=dl, denice=di,
-                                        ray_tracing_on=ray_tracing)
+                                        ray_tracing_on=ray_tracing, o3n=o3)
         except ValueError as err:
             valid[i] = 3 if "RayTrac" in str(err) else 2
             continue

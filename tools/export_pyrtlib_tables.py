@@ -5,7 +5,7 @@ Run this where pyrtlib is installed (it is NOT in the build image, so this scrip
 executed there: treat it as a starting point and check the attribute names against your
 pyrtlib version).  It closes the "parity unpinned" gap of DESIGN.md section 2 with data, not code:
 
-    python tools/export_pyrtlib_tables.py R24 [--set key=value ...] [--o2-post-scale X] > R24_pyrtlib.json
+    python tools/export_pyrtlib_tables.py R24 [--o3] [--set key=value ...] [--o2-post-scale X] > R24_pyrtlib.json
     >>> from mwr_fast_forward_operators_and_lbls_amd import spectroscopy as sp
     >>> sp.register_model(sp.ModelTables.from_json(open("R24_pyrtlib.json").read()), overwrite=True)
 
@@ -16,6 +16,12 @@ literature and listed under "_unverified_scalars" in the output: check each agai
 pyrtlib's absorption_model.py and correct it with ``--set key=value``.  A constant factor your
 pyrtlib applies to the O2 sum and this schema has no field for (e.g. the 1.004 isotopologue factor of
 newer o2abs releases) goes in with ``--o2-post-scale``: it is folded into o2_coef.
+
+``--o3`` also dumps pyrtlib's ozone line list (O3AbsModel.o3ll) into the record's ``xlines`` (fl, s1, b, w, x), which is
+what lets ``TbCloudRTE(..., o3n=...)`` / ``mwrt_tb_options.o3n`` run (without a table that call is refused).  The scalars
+of the ozone routine (x_reft, x_qvib_t, x_mass, x_coef) are hard-coded from Rosenkranz's o3abs as recalled and listed
+as unverified: compare them, and the formula in include/mwrt.h (mwrt_model_desc.n_x), with your pyrtlib's
+``O3AbsModel.o3_absorption`` before trusting an ozone TB.
 """
 import json
 import sys
@@ -49,7 +55,16 @@ def apply_overrides(out: dict, sets, o2_post_scale: float = 1.0) -> dict:
     return out
 
 
-def main(model: str, sets=(), o2_post_scale: float = 1.0):
+def o3_record(ll) -> dict:
+    """pyrtlib's ozone line list object -> the ``xlines`` dict (pure attribute reads: testable with a stand-in).
+    Attribute names as in Rosenkranz's o3abs line file: fl [GHz], s1 [cm^2 Hz at the reference temperature], b
+    (temperature coefficient of the strength), w [GHz/mb] air half width, x its temperature exponent."""
+    n = len(np.atleast_1d(getattr(ll, "fl")))
+    return {"fl": arr(ll, "fl"), "s1": arr(ll, "s1", "s"), "b": arr(ll, "b", "b2", n=n), "w": arr(ll, "w", "w0", "w3"),
+            "x": arr(ll, "x", n=n)}
+
+
+def main(model: str, sets=(), o2_post_scale: float = 1.0, with_o3: bool = False):
     from pyrtlib.absorption_model import H2OAbsModel, O2AbsModel  # noqa: F401 (needs pyrtlib)
 
     H2OAbsModel.model = model
@@ -97,6 +112,15 @@ def main(model: str, sets=(), o2_post_scale: float = 1.0):
     for k, attr in (("o2_x", "x"), ("o2_wb300", "wb300")):
         if not hasattr(o, attr):
             out["_unverified_scalars"].append(k)
+    if with_o3:
+        from pyrtlib.absorption_model import O3AbsModel
+        O3AbsModel.model = model
+        O3AbsModel.set_ll()
+        ll = O3AbsModel.o3ll
+        out["xlines"] = o3_record(ll)
+        out["x_reft"] = float(getattr(ll, "reftline", 296.0))
+        out["x_qvib_t"], out["x_mass"], out["x_coef"] = 1008.0, 48.0, 1.0e-10 / 3.14159265358979
+        out["_unverified_scalars"] += ["x_qvib_t", "x_mass", "x_coef"] + ([] if hasattr(ll, "reftline") else ["x_reft"])
     out = apply_overrides(out, sets, o2_post_scale)
     print(json.dumps(out, indent=1))
     print("# unverified scalar switches (hard-coded per model name, NOT read from pyrtlib): "
@@ -109,5 +133,6 @@ if __name__ == "__main__":
     ap.add_argument("model", nargs="?", default="R24")
     ap.add_argument("--set", action="append", default=[], metavar="KEY=VALUE")
     ap.add_argument("--o2-post-scale", type=float, default=1.0)
+    ap.add_argument("--o3", action="store_true", help="also dump the ozone line list (O3AbsModel.o3ll) into xlines")
     a = ap.parse_args()
-    main(a.model, a.set, a.o2_post_scale)
+    main(a.model, a.set, a.o2_post_scale, a.o3)
