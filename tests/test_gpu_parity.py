@@ -114,7 +114,10 @@ def test_nan_in_nan_out(gpu_ctx):
         Q = {k: v.copy() for k, v in P.items()}
         Q[fld][prof, lev] = np.nan
         tb, valid, ex = gpu_ctx.tb_batch("R24", Q["z"], Q["p"], Q["t"], Q["rh"], pr.HATPRO_FRQS, ang, extras=True)
-        assert valid[prof] == 0 and np.isnan(tb[prof]).all() and np.isnan(ex["tauwet"][prof]).all()
+        assert valid[prof] == 0 and np.isnan(tb[prof]).all()
+        for col in ("tbatm", "tmr", "tauwet", "taudry", "tauliq", "tauice"):      # every column of a blanked profile is NaN,
+            assert np.isnan(ex[col][prof]).all(), col                               # the clear-sky cloud columns included
+        assert np.isnan(ex["taulay"][prof]).all()
         keep = np.arange(8) != prof
         assert (valid[keep] == 1).all() and np.array_equal(tb[keep], clean[keep])
     f = pr.HATPRO_FRQS.copy(); f[3] = np.nan
@@ -125,8 +128,9 @@ def test_nan_in_nan_out(gpu_ctx):
         keep = ~np.isnan(a)
         tb, valid, ex = gpu_ctx.tb_batch("R24", P["z"], P["p"], P["t"], P["rh"], pr.HATPRO_FRQS, a, extras=True)
         assert np.isnan(tb[:, bad, :]).all() and (valid == 1).all()
-        for k in ("tbatm", "tmr", "tauwet", "taudry"):
+        for k in ("tbatm", "tmr", "tauwet", "taudry", "tauliq", "tauice"):
             assert np.isnan(ex[k][:, bad, :]).all() and not np.isnan(ex[k][:, keep, :]).any()
+        assert (ex["tauliq"][:, keep, :] == 0.0).all() and (ex["tauice"][:, keep, :] == 0.0).all()    # clear sky
         assert not np.isnan(ex["taulay"]).any()                # zenith layer depths carry no angle
         # the surviving angles: same numbers (to the elevation-mates note of include/mwrt.h -- with 4.2 degrees
         # gone a wave may take the thin-layer form it could not take before)
@@ -218,6 +222,30 @@ def test_full_size_properties_config3(gpu_ctx):
     for i in (0, 517, 999):
         ref, _ = oracle_tb(m, P, i, frq, ang)
         assert np.abs(tb[i] - ref["tbtotal"]).max() <= TOL_K
+
+
+def test_full_size_properties_config2(gpu_ctx):
+    """BASELINE configs[1] at full size (1000 x 14 x 1, zenith): the one-elevation launch takes K2's per-step vote path
+    (short segments) -- its TBs equal the zenith rows of the 7-elevation call to the elevation-mates note (1e-10 K), are
+    bitwise invariant under batch slicing and permutation, physically bounded, and a sample meets the oracle."""
+    from oracle import c_oracle
+    P = pr.synthetic_profiles(1000, 2)
+    frq, zen = pr.HATPRO_FRQS, np.array([90.0])
+    tb, valid = gpu_ctx.tb_batch("R24", P["z"], P["p"], P["t"], P["rh"], frq, zen)
+    assert tb.shape == (1000, 1, 14) and (valid == 1).all() and np.isfinite(tb).all()
+    assert (tb > 2.7).all() and (tb < P["t"].max() + 1e-6).all()
+    assert (tb[:, 0, 13] > tb[:, 0, 6]).all()                      # 58 GHz (opaque) warmer than the 31.4-GHz window
+    seven, _ = gpu_ctx.tb_batch("R24", P["z"], P["p"], P["t"], P["rh"], frq, pr.BENCH_ELEVATIONS_7)
+    assert np.abs(seven[:, 0, :] - tb[:, 0, :]).max() <= 1e-10
+    part, _ = gpu_ctx.tb_batch("R24", P["z"][137:402], P["p"][137:402], P["t"][137:402], P["rh"][137:402], frq, zen)
+    assert np.array_equal(part, tb[137:402])
+    perm = np.random.default_rng(3).permutation(1000)
+    shuf, _ = gpu_ctx.tb_batch("R24", P["z"][perm], P["p"][perm], P["t"][perm], P["rh"][perm], frq, zen)
+    assert np.array_equal(shuf, tb[perm])
+    m = sp.get_model("R24")
+    for i in (0, 499, 999):
+        ref = c_oracle.tb_profile(m, P["z"][i], P["p"][i], P["t"][i], P["rh"][i], frq, zen)["tbtotal"]
+        assert np.abs(tb[i, 0] - ref).max() <= TOL_K
 
 
 def test_device_pointer_entry(gpu_ctx):
@@ -1131,16 +1159,17 @@ def test_layer_step_forms_agree(gpu_ctx, nlev, ang):
 @pytest.mark.gpu
 @pytest.mark.parametrize("mode", ["", "opt", "fine", "extras"])
 def test_randomised_parity_hunt_short(gpu_ctx, mode):
-    """Ten seconds of tools/fuzz_parity.py per mode (random level counts, elevation and frequency sets, models,
-    extreme columns; cloud / ray tracing; fine grids; every output column) against the C oracle.  The long runs are
-    in profiles/r02_fuzz_parity.txt."""
+    """A fixed NUMBER of random calls of tools/fuzz_parity.py per mode (random level counts, elevation and frequency
+    sets, models, extreme columns; cloud / ray tracing; fine grids; every output column) against the C oracle -- count-boxed,
+    so the coverage does not depend on the speed of the box.  The long runs are in profiles/r0*_fuzz_parity.txt."""
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    cmd = [sys.executable, os.path.join(root, "tools", "fuzz_parity.py"), "10", "5"] + ([mode] if mode else [])
-    r = subprocess.run(cmd, cwd=root, capture_output=True, text=True, timeout=300)
+    ncalls = {"": 60, "opt": 40, "fine": 30, "extras": 40}[mode]
+    cmd = [sys.executable, os.path.join(root, "tools", "fuzz_parity.py"), f"calls={ncalls}", "5"] + ([mode] if mode else [])
+    r = subprocess.run(cmd, cwd=root, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-1500:])
-    assert "fuzz ok" in r.stdout
+    assert f"fuzz ok: {ncalls} calls" in r.stdout
 
 
 def _layer_tau_pair(gpu_ctx, model, P, frq, ang, mode=0):

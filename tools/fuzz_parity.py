@@ -6,6 +6,8 @@ perturbations (dry / saturated columns, cold stratospheres), for a wall-clock bu
 fails (exit 1) on anything above 1e-6 K or a validity-flag mismatch.
 
     python tools/fuzz_parity.py [seconds] [seed] [opt]      (opt: also cloud liquid / ice and ray tracing, randomly)
+    python tools/fuzz_parity.py calls=N [seed] [mode]       a fixed NUMBER of random calls instead of a time budget
+                                                            (what the test suite runs: its coverage does not depend on the box)
 """
 import sys, os, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -15,7 +17,11 @@ warnings.simplefilter("ignore")
 from mwr_fast_forward_operators_and_lbls_amd import _native, profiles as pr, spectroscopy as sp
 from oracle import c_oracle as co
 
-budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
+max_calls = None
+if len(sys.argv) > 1 and sys.argv[1].startswith("calls="):
+    max_calls, budget = int(sys.argv[1][6:]), 1e9
+else:
+    budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
 seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 with_opt = len(sys.argv) > 3 and sys.argv[3] == "opt"
 extras = len(sys.argv) > 3 and sys.argv[3] == "extras"    # every DataFrame column of execute()
@@ -27,7 +33,7 @@ models = ["R98", "R17", "R20", "R20SD", "R24"]
 centres = np.array([22.235, 50.474, 53.067, 56.264, 58.447, 60.306, 62.486, 118.750, 183.310])
 worst, cases, evals = 0.0, 0, 0
 t_end = time.time() + budget
-while time.time() < t_end:
+while time.time() < t_end and (max_calls is None or cases < max_calls):
     nlev = int(rng.choice([20, 33, 64, 65, 100, 180, 180, 180, 257, 400]))
     nprof = int(rng.integers(1, 6))
     P = pr.synthetic_profiles(nprof, int(rng.integers(0, 10**6)), nlev=nlev)
@@ -106,4 +112,4 @@ while time.time() < t_end:
             worst = max(worst, dev); evals += ref.size
     cases += 1
 tag = ", with cloud / ray tracing" if with_opt else (", fine grids (windowed path)" if fine else (", all columns" if extras else (", up to 64 elevations" if wide else "")))
-print(f"fuzz ok: {cases} calls, {evals} TB evaluations checked against oracle/lbl_oracle.c, worst |dTB| = {worst:.3e} K (seed {seed}, {budget:.0f} s{tag})")
+print(f"fuzz ok: {cases} calls, {evals} TB evaluations checked against oracle/lbl_oracle.c, worst |dTB| = {worst:.3e} K (seed {seed}, {(str(max_calls) + ' calls') if max_calls else f'{budget:.0f} s'}{tag})")
