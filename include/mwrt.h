@@ -290,6 +290,23 @@ int mwrt_tb_from_layer_tau_device(mwrt_context* ctx, const mwrt_model* model,
                                   int32_t nf, const double* frq_ghz, int32_t nang, const double* elev_deg,
                                   const uint8_t* d_valid, double* d_tb_out, void* stream);
 
+/* K-matrix of the operator in ONE call: the block the reference parses out of RTTOV-gb's K run
+ * (python_src/proc/RTTOV_gb_processing.py:286-300, :418-432: dTB/dT, dTB/dq per level and channel).  Partial derivatives
+ * of every TB with respect to the LBL inputs of each level, [nprof][nang][nf][nlev]:
+ *   dtb_dt   K/K      d TB / d T_i       at fixed vapour pressure e_i, pressure and heights
+ *   dtb_de   K/hPa    d TB / d e_i       (e = rh * es(T), Goff-Gratch) at fixed T_i
+ *   dtb_ddz  K/km     d TB / d (z_i - z_{i-1})   thickness of the layer below level i (entry 0 = 0)
+ * The absorption of a level is a local function of (p, T, e): its derivatives are central differences of five
+ * evaluations per level (T +- 0.01 K, e (1 +- 1e-4)); the layer rule (exponential_integration), the Planck-space recursion
+ * and bright() are differentiated analytically (adjoint), so the cost is ~6 forward runs whatever nlev -- not the
+ * 3 nlev + 1 forward runs of a brute-force K-matrix.  Clear sky, plane-parallel.  HOST buffers, synchronous; tb_out as
+ * mwrt_tb_batch; valid_out as there (0 / 2: that profile's outputs are NaN). */
+int mwrt_tb_jacobian_batch(mwrt_context* ctx, const mwrt_model* model,
+                           int64_t nprof, int32_t nlev,
+                           const double* z_km, const double* p_hpa, const double* t_k, const double* rh_frac,
+                           int32_t nf, const double* frq_ghz, int32_t nang, const double* elev_deg,
+                           double* tb_out, double* dtb_dt, double* dtb_de, double* dtb_ddz, uint8_t* valid_out);
+
 /* Diagnostic: evaluates the kernels' own exp / log / division helpers (fexp, flog, fdiv, fdiv1) on
  * host arrays x[n], y_pos[n] (y > 0), so their accuracy can be checked against libm. */
 int mwrt_selftest_math(mwrt_context* ctx, int32_t n, const double* x, const double* y_pos,

@@ -77,6 +77,8 @@ SIGNATURES = {
     "mwrt_layer_tau_batch_device": (ctypes.c_int, [_vp, _vp, _i64, _i32, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _i32, _vp, _vp]),
     "mwrt_tb_from_layer_tau_device": (ctypes.c_int, [_vp, _vp, _i64, _i32, _vp, _i32, _vp, _i32, _vp, _i32, _vp, _vp, _vp,
                                                      _vp]),
+    "mwrt_tb_jacobian_batch": (ctypes.c_int, [_vp, _vp, _i64, _i32, _vp, _vp, _vp, _vp, _i32, _vp, _i32, _vp, _vp, _vp, _vp,
+                                              _vp, _vp]),
     "mwrt_set_absorption_mode": (ctypes.c_int, [_vp, ctypes.c_int]),
     "mwrt_selftest_math": (ctypes.c_int, [_vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp]),
     "mwrt_synchronize": (ctypes.c_int, [_vp, _vp]),
@@ -318,6 +320,26 @@ class Context:
             self._handle, self.model(model), nprof, nlev, _ptr(p), _ptr(t), _ptr(rh),
             frq.size, _ptr(frq), _ptr(awet), _ptr(adry)), "mwrt_absorption_batch")
         return awet, adry
+
+    @_serialised
+    def tb_jacobian_batch(self, model, z, p, t, rh, frq, elev):
+        """K-matrix in one call (include/mwrt.h mwrt_tb_jacobian_batch): returns ``tb [nprof][nang][nf]``, ``valid`` and a
+        dict of ``dtb_dt`` [K/K at fixed e], ``dtb_de`` [K/hPa], ``dtb_ddz`` [K/km of layer thickness], each
+        ``[nprof][nang][nf][nlev]`` (levels ground -> top)."""
+        z = _f64(z)
+        if z.ndim != 2:
+            raise ValueError("profiles must be [nprof][nlev]")
+        nprof, nlev = z.shape
+        p, t, rh = _f64(p, z.shape, "p"), _f64(t, z.shape, "t"), _f64(rh, z.shape, "rh")
+        frq, elev = _f64(frq).ravel(), _f64(elev).ravel()
+        nf, nang = frq.size, elev.size
+        tb = np.empty((nprof, nang, nf))
+        jac = {k: np.empty((nprof, nang, nf, nlev)) for k in ("dtb_dt", "dtb_de", "dtb_ddz")}
+        valid = np.empty(nprof, dtype=np.uint8)
+        self._check(self._lib.mwrt_tb_jacobian_batch(
+            self._handle, self.model(model), nprof, nlev, _ptr(z), _ptr(p), _ptr(t), _ptr(rh), nf, _ptr(frq), nang, _ptr(elev),
+            _ptr(tb), _ptr(jac["dtb_dt"]), _ptr(jac["dtb_de"]), _ptr(jac["dtb_ddz"]), _ptr(valid)), "mwrt_tb_jacobian_batch")
+        return tb, valid, jac
 
     # -- device-buffer entry points (raw device addresses, e.g. torch.Tensor.data_ptr()) -------
     @_serialised

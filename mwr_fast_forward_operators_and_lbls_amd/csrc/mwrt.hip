@@ -1056,6 +1056,101 @@ int mwrt_tb_from_layer_tau_device(mwrt_context* c, const mwrt_model* m, int64_t 
   return rte_tau_launch(c, m, nprof, nlev, d_tau, tau_pitch, d_t, nf, dev_frq, nang, dev_am, d_tb, d_valid, st);
 }
 
+// K-matrix (dTB/dT, dTB/de, dTB/d thickness per level) -- see k_tb_jacobian.  HOST buffers, synchronous.
+int mwrt_tb_jacobian_batch(mwrt_context* c, const mwrt_model* m, int64_t nprof, int32_t nlev,
+                           const double* z, const double* p, const double* t, const double* rh,
+                           int32_t nf, const double* frq, int32_t nang, const double* elev,
+                           double* tb, double* dtb_dt, double* dtb_de, double* dtb_ddz, uint8_t* valid) {
+  int rc = check_common(c, m, nprof, nlev, nf);
+  if (rc) return rc;
+  if (nang < 1 || nang > MWRT_MAX_ANGLES) return fail(MWRT_ERR_INVALID_ARGUMENT, "nang out of range");
+  if (!z || !p || !t || !rh || !frq || !elev || !tb || !dtb_dt || !dtb_de || !dtb_ddz || !valid)
+    return fail(MWRT_ERR_INVALID_ARGUMENT, "null buffer");
+  if (any_nan(frq, nf)) return fail(MWRT_ERR_INVALID_ARGUMENT, "NaN frequency");
+  if (nprof == 0) return MWRT_OK;
+  HIP_TRY(hipSetDevice(c->device));
+  hipStream_t st = c->stream;
+  std::vector<double> am;
+  rc = airmass_of(elev, nang, &am); if (rc) return rc;
+  const double *dev_frq = nullptr, *dev_am = nullptr;
+  rc = upload_small(c, c->frq_cache, frq, nf, &dev_frq); if (rc) return rc;
+  rc = upload_small(c, c->am_cache, am.data(), nang, &dev_am); if (rc) return rc;
+  constexpr double DT = 0.01, REL_E = 1e-4, MIN_DE = 1e-7;       // local steps of the absorption derivatives
+  // Goff-Gratch over water, as RTEquation.vapor [EXT] (host copy: only used to keep e fixed while T moves)
+  auto es_of = [](double tk) {
+    const double y = 373.16 / tk;
+    const double es = -7.90298 * (y - 1.0) + 5.02808 * std::log10(y) - 1.3816e-07 * (std::pow(10.0, 11.344 * (1.0 - (1.0 / y))) - 1.0) +
+                      0.0081328 * (std::pow(10.0, -3.49149 * (y - 1.0)) - 1.0) + std::log10(1013.246);
+    return std::pow(10.0, es);
+  };
+  // profile batches: the five absorption sets + three Jacobian arrays of one batch stay under ~1 GiB
+  const size_t per_prof = sizeof(double) * ((size_t)10 * nf * nlev + (size_t)3 * nang * nf * nlev + (size_t)nang * nf + 12 * (size_t)nlev) + 1;
+  const int64_t batch = std::max<int64_t>(1, std::min<int64_t>(nprof, (int64_t)(((size_t)1 << 30) / per_prof)));
+  DevBuf ws;                                                      // own workspace: freed on return
+  HIP_TRY(ws.reserve((size_t)batch * per_prof + 4096));
+  for (int64_t b0 = 0; b0 < nprof; b0 += batch) {
+    const int64_t nb = std::min(batch, nprof - b0);
+    const size_t nin = (size_t)nb * nlev, nabs = (size_t)nb * nf * nlev, njac = (size_t)nb * nang * nf * nlev, ntb = (size_t)nb * nang * nf;
+    // host side: the 12 level arrays  z p t rh | t+ rh(T+) | t- rh(T-) | rh(e+) rh(e-) | de | (pad)
+    std::vector<double> h(12 * nin);
+    double *hz = h.data(), *hp = hz + nin, *ht = hp + nin, *hrh = ht + nin, *htp = hrh + nin, *hrp = htp + nin, *htm = hrp + nin,
+           *hrm = htm + nin, *hep = hrm + nin, *hem = hep + nin, *hde = hem + nin;
+    for (size_t i = 0; i < nin; ++i) {
+      const size_t g = (size_t)b0 * nlev + i;
+      hz[i] = z[g]; hp[i] = p[g]; ht[i] = t[g]; hrh[i] = rh[g];
+      const double es = es_of(t[g]), e = rh[g] * es;
+      htp[i] = t[g] + DT; hrp[i] = e / es_of(t[g] + DT);
+      htm[i] = t[g] - DT; hrm[i] = e / es_of(t[g] - DT);
+      const double de = std::max(std::fabs(e) * REL_E, MIN_DE);
+      const double lo = std::max(e - de, 0.0);                     // a dry level: the step stays on the non-negative side
+      hep[i] = (lo + 2.0 * de) / es; hem[i] = lo / es; hde[i] = de;
+    }
+    double* base = ws.as<double>();
+    double* d_lev = base;                                          // 12 x nin
+    double* d_abs = d_lev + 12 * nin;                              // 10 x nabs
+    double* d_jac = d_abs + 10 * nabs;                             // 3 x njac
+    double* d_tb = d_jac + 3 * njac;
+    uint8_t* d_valid = (uint8_t*)(d_tb + ntb);
+    HIP_TRY(hipMemcpyAsync(d_lev, h.data(), sizeof(double) * 12 * nin, hipMemcpyHostToDevice, st));
+    const double *dz_ = d_lev, *dp_ = d_lev + nin, *dt_ = d_lev + 2 * nin, *drh_ = d_lev + 3 * nin;
+    const double* T_of[5] = {dt_, d_lev + 4 * nin, d_lev + 6 * nin, dt_, dt_};
+    const double* RH_of[5] = {drh_, d_lev + 5 * nin, d_lev + 7 * nin, d_lev + 8 * nin, d_lev + 9 * nin};
+    JacArgs a{};
+    for (int v = 0; v < 5; ++v) {
+      double* aw = d_abs + (size_t)(2 * v) * nabs; double* ad = aw + nabs;
+      rc = mwrt_absorption_batch_device(c, m, nb, nlev, dp_, T_of[v], RH_of[v], nf, frq, aw, ad, st);
+      if (rc) return rc;
+      a.a[v][0] = aw; a.a[v][1] = ad;
+    }
+    a.M = m->d_desc; a.z = dz_; a.t = dt_; a.de = d_lev + 10 * nin; a.dT = DT; a.frq = dev_frq; a.airmass = dev_am;
+    a.tb = d_tb; a.dtb_dt = d_jac; a.dtb_de = d_jac + njac; a.dtb_ddz = d_jac + 2 * njac; a.valid = d_valid;
+    a.nprof = nb; a.nlev = nlev; a.nf = nf; a.nang = nang;
+    HIP_TRY(hipMemsetAsync(d_valid, 1, (size_t)nb, st));
+    const int64_t nthreads = nb * nf * nang;
+    timing_begin(c, st);
+    hipLaunchKernelGGL(k_tb_jacobian, dim3((unsigned)((nthreads + 63) / 64)), dim3(64), 0, st, a);
+    timing_end(c, st);
+    HIP_TRY(hipGetLastError());
+    const size_t o = (size_t)b0 * nang * nf;
+    HIP_TRY(hipMemcpyAsync(tb + o, d_tb, sizeof(double) * ntb, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(dtb_dt + o * nlev, a.dtb_dt, sizeof(double) * njac, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(dtb_de + o * nlev, a.dtb_de, sizeof(double) * njac, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(dtb_ddz + o * nlev, a.dtb_ddz, sizeof(double) * njac, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(valid + b0, d_valid, (size_t)nb, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+  }
+  ws.release();
+  // a profile flagged 0 / 2 is blanked as a whole, whichever thread met it
+  const double qnan = std::nan("");
+  for (int64_t i = 0; i < nprof; ++i) {
+    if (valid[i] == 1) continue;
+    const size_t o = (size_t)i * nang * nf;
+    for (size_t k = 0; k < (size_t)nang * nf; ++k) tb[o + k] = qnan;
+    for (size_t k = 0; k < (size_t)nang * nf * nlev; ++k) { dtb_dt[o * nlev + k] = qnan; dtb_de[o * nlev + k] = qnan; dtb_ddz[o * nlev + k] = qnan; }
+  }
+  return MWRT_OK;
+}
+
 int mwrt_set_absorption_mode(mwrt_context* c, int mode) {
   if (!c || mode < 0 || mode > 2) return fail(MWRT_ERR_INVALID_ARGUMENT, "mode must be 0, 1 or 2");
   c->absorption_mode = mode;

@@ -16,8 +16,9 @@ RTTOV-gb profiles carry no geometric height: it is rebuilt hydrostatically from 
 the station height, and humidity converts as e = ppmv * p / 1e6 (the reference's own
 ``rh2ppmv`` / ``ppmv2rh``, preprocessing4all.py:124-136) with pyrtlib's Goff-Gratch e_s.
 The K-matrix block the reference also parses (:286-300: per channel a header of three lines, then one row
-``level p dTB/dT dTB/dppmv dTB/dliq`` per level) is produced by ``jacobians`` (central / forward differences
-through the batched operator) and written / read by ``format_jacobians`` / ``parse_jacobians``.  Liquid water
+``level p dTB/dT dTB/dppmv dTB/dliq`` per level) is produced by ``jacobians`` (one call of the operator's
+adjoint, ``mwrt_tb_jacobian_batch``; central / forward differences through the batched operator for the liquid column) and
+written / read by ``format_jacobians`` / ``parse_jacobians``.  Liquid water
 enters through the cloud-liquid opt-in of the LBL operator (``clear_sky=False``; the reference itself runs RTTOV-gb
 with ``clear_sky_bool=True``, :82-86, so the default here is clear sky too).
 """
@@ -145,9 +146,42 @@ def simulate(profiles: List[dict], model: str = "R24", frqs=HATPRO_FRQS, clear_s
     return {"tbs": tbs, "tau_total": trans, "tau_levels": trans_lev, "valid": valid}
 
 
+def jacobians_adjoint(profile: dict, model: str = "R24", frqs=HATPRO_FRQS):
+    """K-matrix of one profile from ONE call of the operator's adjoint (``mwrt_tb_jacobian_batch``): the partial
+    derivatives with respect to the LBL inputs of each level (T at fixed vapour pressure, vapour pressure, layer
+    thickness) chained to RTTOV-gb's variables -- T at fixed ppmv, ppmv -- through e = ppmv p / 1e6 and the hydrostatic
+    heights this module rebuilds (``to_lbl_inputs``): a level's virtual temperature sets the thickness of the two layers
+    that touch it.  Returns ``(dTB_dT [nlev][nchan] K/K, dTB_dq [nlev][nchan] K/ppmv)``, levels TOP -> GROUND, like
+    ``jacobians`` -- which it matches to the accuracy of that function's finite differences."""
+    z, p, t, rh, elev = to_lbl_inputs([profile])
+    tables = spectroscopy.get_model(model)
+    tb, valid, jac = _native.default_context().tb_jacobian_batch(tables, z, p, t, rh, np.asarray(frqs, dtype=float), elev[:1])
+    if valid[0] != 1:
+        raise ValueError("the profile was rejected")
+    p, t = p[0], t[0]
+    e = profile["ppmv"][::-1] * p / 1e6
+    q = 0.622 * e / (p - 0.378 * e)
+    g, rd = 9.80665, 287.04
+    # thickness of the layer below level m: dz_m = rd/g * (tv_m + tv_{m-1})/2 * ln(p_{m-1}/p_m) / 1000
+    half = np.zeros_like(p)
+    half[1:] = rd / g * 0.5 * np.log(p[:-1] / p[1:]) / 1000.0            # d dz_m / d tv_m = d dz_m / d tv_{m-1}
+    ddz = jac["dtb_ddz"][0, 0]                                            # [nf][nlev]
+    dtb_dtv = ddz * half[None, :]                                         # through the layer below the level ...
+    dtb_dtv[:, :-1] += ddz[:, 1:] * half[None, 1:]                        # ... and the layer above it
+    dtv_dt = 1.0 + 0.608 * q
+    dtv_dq = 0.608 * t
+    dq_de = 0.622 * p / (p - 0.378 * e) ** 2
+    de_dppmv = p / 1e6
+    d_t = jac["dtb_dt"][0, 0] + dtb_dtv * dtv_dt[None, :]
+    d_q = (jac["dtb_de"][0, 0] + dtb_dtv * (dtv_dq * dq_de)[None, :]) * de_dppmv[None, :]
+    return d_t.T[::-1].copy(), d_q.T[::-1].copy()
+
+
 def jacobians(profile: dict, model: str = "R24", frqs=HATPRO_FRQS, dT: float = 0.05, rel_q: float = 0.01,
-              liquid: bool = False, d_liq: float = 1e-5):
-    """Brute-force K-matrix of one profile by central differences through the batched operator.
+              liquid: bool = False, d_liq: float = 1e-5, method: str = "auto"):
+    """K-matrix of one profile.  ``method="adjoint"`` (what "auto" picks for the clear-sky block): one call of the
+    operator's adjoint, see ``jacobians_adjoint``.  ``method="fd"`` (what "auto" picks with ``liquid=True``): brute
+    force, central differences through the batched operator.
 
     RTTOV-gb's K run (the block the reference parses at RTTOV_gb_processing.py:264-283) returns
     dTB/dx per level; a tangent-linear kernel does not exist yet, but one launch over the
@@ -161,6 +195,12 @@ def jacobians(profile: dict, model: str = "R24", frqs=HATPRO_FRQS, dT: float = 0
     for cloud empties a layer with a cloud-free end (zeroflg = False), so a level's liquid acts only together with a
     cloudy neighbour: the column is exactly zero in clear air away from cloud.
     """
+    if method not in ("auto", "adjoint", "fd"):
+        raise ValueError("method must be 'auto', 'adjoint' or 'fd'")
+    if method == "adjoint" and liquid:
+        raise ValueError("the adjoint K-matrix is clear sky; use method='fd' for the liquid column")
+    if method == "adjoint" or (method == "auto" and not liquid):
+        return jacobians_adjoint(profile, model, frqs)
     nlev = len(profile["p"])
     copies = []
     for sign in (+1.0, -1.0):

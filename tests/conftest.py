@@ -45,6 +45,39 @@ class OracleContext:
                                       denliq=denliq, denice=denice, ray_tracing=ray_tracing, o3n=o3n)
         return (tb, valid, ex) if extras else (tb, valid)
 
+    def tb_jacobian_batch(self, model, z, p, t, rh, frq, elev):
+        """The K-matrix entry, CPU stand-in: the same partial derivatives (T at fixed e, e, layer thickness) by central
+        differences through the oracle -- one profile at a time, 6 nlev oracle runs each: small cases only."""
+        import numpy as np
+        from mwr_fast_forward_operators_and_lbls_amd import spectroscopy
+        from oracle import c_oracle, lbl_oracle
+        tables = spectroscopy.get_model(model) if isinstance(model, str) else model
+        z, p, t, rh = (np.ascontiguousarray(a, dtype=float) for a in (z, p, t, rh))
+        frq, elev = np.asarray(frq, dtype=float).ravel(), np.asarray(elev, dtype=float).ravel()
+        nprof, nlev = z.shape
+        nf, nang = len(frq), len(elev)
+        tb = np.empty((nprof, nang, nf))
+        jac = {k: np.zeros((nprof, nang, nf, nlev)) for k in ("dtb_dt", "dtb_de", "dtb_ddz")}
+
+        def run(zz, tt, rr, i):
+            return c_oracle.tb_profile(tables, zz, p[i], tt, rr, frq, elev)["tbtotal"].reshape(nang, nf)
+        for i in range(nprof):
+            tb[i] = run(z[i], t[i], rh[i], i)
+            es = lbl_oracle.vapor(t[i], np.ones(nlev))[0]
+            e = rh[i] * es
+            for l in range(nlev):
+                dT, de, dz = 0.02, max(1e-4 * e[l], 1e-7), 1e-4
+                tp, tm = t[i].copy(), t[i].copy(); tp[l] += dT; tm[l] -= dT
+                rp, rm = rh[i].copy(), rh[i].copy()
+                rp[l] = e[l] / lbl_oracle.vapor(tp[l:l + 1], np.ones(1))[0][0]; rm[l] = e[l] / lbl_oracle.vapor(tm[l:l + 1], np.ones(1))[0][0]
+                jac["dtb_dt"][i, :, :, l] = (run(z[i], tp, rp, i) - run(z[i], tm, rm, i)) / (2 * dT)
+                rp, rm = rh[i].copy(), rh[i].copy(); rp[l] = (e[l] + de) / es[l]; rm[l] = (e[l] - de) / es[l]
+                jac["dtb_de"][i, :, :, l] = (run(z[i], t[i], rp, i) - run(z[i], t[i], rm, i)) / (2 * de)
+                if l > 0:                      # thicken / thin the layer below level l: everything from l up moves
+                    zp, zm = z[i].copy(), z[i].copy(); zp[l:] += dz; zm[l:] -= dz
+                    jac["dtb_ddz"][i, :, :, l] = (run(zp, t[i], rh[i], i) - run(zm, t[i], rh[i], i)) / (2 * dz)
+        return tb, np.ones(nprof, dtype=np.uint8), jac
+
     def tb_batch_multi(self, models, z, p, t, rh, frq, elev):
         import numpy as np
         res = [self.tb_batch(m, z, p, t, rh, frq, elev) for m in models]

@@ -92,7 +92,7 @@ def test_run_pyrtlib_surface(tmp_path, capsys, oracle_ctx):
 def test_finite_difference_jacobians(oracle_ctx):
     text, _ = rttov_text(nprof=1, nlev=24, elevs=(90.0,))
     prof = rw.parse_profiles(text, 24)[0]
-    d_t, d_q = rw.jacobians(prof, "R98")
+    d_t, d_q = rw.jacobians(prof, "R98", method="fd")
     assert d_t.shape == (24, 14) and d_q.shape == (24, 14)
     # an opaque channel reads the air temperature: its temperature weights sum to ~1 and sit near the ground
     assert abs(d_t[:, 13].sum() - 1.0) < 0.03 and d_t[-6:, 13].sum() > 0.8
@@ -109,6 +109,23 @@ def test_finite_difference_jacobians(oracle_ctx):
         z, p, t, rh, _ = rw.to_lbl_inputs([q])
         tbs.append(lo.tb_cloud_rte(sp.get_model("R98"), z[0], p[0], t[0], rh[0], rw.HATPRO_FRQS, np.array([90.0]))["tbtotal"])
     assert np.allclose(d_t[lv], (tbs[0] - tbs[1]) / 0.1, atol=1e-8)
+
+
+def test_adjoint_jacobians_chain_rule(oracle_ctx):
+    """``jacobians`` (method "auto" = one adjoint call) chains the operator's partial derivatives -- T at fixed vapour
+    pressure, vapour pressure, layer thickness -- to RTTOV-gb's variables (T at fixed ppmv with hydrostatically rebuilt
+    heights, ppmv).  On CPU the partials come from the oracle by differences (conftest stand-in), so this pins the chain
+    rule: it must reproduce the brute-force K-matrix."""
+    text, _ = rttov_text(nprof=1, nlev=24, elevs=(19.2,))
+    prof = rw.parse_profiles(text, 24)[0]
+    a_t, a_q = rw.jacobians(prof, "R17")
+    f_t, f_q = rw.jacobians(prof, "R17", method="fd")
+    assert a_t.shape == f_t.shape == (24, 14)
+    for c in range(14):
+        assert np.abs(a_t[:, c] - f_t[:, c]).max() <= 2e-4 * np.abs(f_t[:, c]).max() + 1e-9, c
+        assert np.abs(a_q[:, c] - f_q[:, c]).max() <= 2e-4 * np.abs(f_q[:, c]).max() + 1e-12, c
+    with pytest.raises(ValueError):
+        rw.jacobians(prof, "R17", liquid=True, method="adjoint")
 
 
 def test_liquid_jacobian_and_k_matrix_text(oracle_ctx):
@@ -141,7 +158,7 @@ def test_liquid_jacobian_and_k_matrix_text(oracle_ctx):
     assert np.allclose(d_l[lv], (pert - base) / 1e-5, rtol=1e-7, atol=1e-4)
     # with no liquid in the profile the T and q columns are the clear-sky ones
     prof0 = dict(prof); prof0["liquid"] = np.zeros(24)
-    d_t0, d_q0 = rw.jacobians(prof0, "R98")
+    d_t0, d_q0 = rw.jacobians(prof0, "R98", method="fd")
     d_t1, d_q1, _ = rw.jacobians(prof0, "R98", liquid=True)
     assert np.allclose(d_t1, d_t0, atol=1e-9) and np.allclose(d_q1, d_q0, atol=1e-12)
     # text round trip, walked the way the reference walks it

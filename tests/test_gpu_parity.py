@@ -514,8 +514,13 @@ def test_jacobians_on_gpu(gpu_ctx):
     from mwr_fast_forward_operators_and_lbls_amd import rttov_gb_wrapper as rw
     text, _ = rttov_text(nprof=1, nlev=180, elevs=(90.0,))
     prof = rw.parse_profiles(text, 180)[0]
-    d_t, d_q = rw.jacobians(prof, "R24")                       # 720 perturbed profiles, one launch per elevation
+    d_t, d_q = rw.jacobians(prof, "R24", method="fd")          # 720 perturbed profiles, one launch per elevation
     assert d_t.shape == (180, 14) and np.isfinite(d_t).all() and np.isfinite(d_q).all()
+    # the adjoint K-matrix (mwrt_tb_jacobian_batch: ~6 forward runs instead of 721) reproduces the brute-force one
+    a_t, a_q = rw.jacobians(prof, "R24")
+    for c in range(14):
+        assert np.abs(a_t[:, c] - d_t[:, c]).max() <= 1e-4 * np.abs(d_t[:, c]).max(), c
+        assert np.abs(a_q[:, c] - d_q[:, c]).max() <= 1e-4 * np.abs(d_q[:, c]).max(), c
     assert abs(d_t[:, 13].sum() - 1.0) < 0.03                  # 58 GHz: temperature weights integrate to one
     assert (d_q[-60:, 0] > 0).all()                            # 22.24 GHz warms with boundary-layer humidity
     # third K-matrix column (liquid water, through the cloud opt-in) on top of a cloud between levels 130 and 150
@@ -525,6 +530,31 @@ def test_jacobians_on_gpu(gpu_ctx):
     assert (d_l[130:150, :7] > 0).all() and (d_l[:129] == 0).all() and (d_l[151:] == 0).all()
     jac = rw.parse_jacobians(rw.format_jacobians(prof["p"], d_t2, d_q2, d_l), 180)
     assert np.allclose(jac[:, :, 3], d_l, rtol=1e-9)
+
+
+def test_k_matrix_entry_against_oracle_differences(gpu_ctx):
+    """mwrt_tb_jacobian_batch: dTB/dT (fixed e), dTB/de, dTB/d(layer thickness) per level from the adjoint of the layer
+    rule + RTE with locally differenced absorption, against central differences through the ORACLE (the conftest
+    stand-in), for a slant and a zenith path, several models, a batch with a NaN profile; TBs equal the forward call."""
+    from conftest import OracleContext
+    ang = np.array([90.0, 8.4])
+    frq = pr.HATPRO_FRQS[[0, 3, 6, 7, 9, 13]]
+    for name, nlev in (("R24", 40), ("R98", 33)):
+        P = pr.synthetic_profiles(3, 77, nlev=nlev)
+        tb, valid, jac = gpu_ctx.tb_jacobian_batch(name, P["z"], P["p"], P["t"], P["rh"], frq, ang)
+        fwd, _ = gpu_ctx.tb_batch(name, P["z"], P["p"], P["t"], P["rh"], frq, ang)
+        assert (valid == 1).all() and np.abs(tb - fwd).max() <= 1e-9
+        _, _, ref = OracleContext().tb_jacobian_batch(name, P["z"][1:2], P["p"][1:2], P["t"][1:2], P["rh"][1:2], frq, ang)
+        for k in ("dtb_dt", "dtb_de", "dtb_ddz"):
+            got, want = jac[k][1], ref[k][0]
+            scale = np.abs(want).max(axis=-1, keepdims=True)
+            assert np.abs(got - want).max() <= 2e-5 * scale.max(), (name, k)
+            assert (np.abs(got - want).max(axis=-1, keepdims=True) <= 1e-3 * scale + 1e-7).all(), (name, k)   # row by row (FD noise floor)
+    Q = {k: v.copy() for k, v in P.items()}
+    Q["t"][2, 5] = np.nan
+    tb, valid, jac = gpu_ctx.tb_jacobian_batch("R98", Q["z"], Q["p"], Q["t"], Q["rh"], frq, np.array([90.0, np.nan]))
+    assert valid.tolist() == [1, 1, 0] and np.isnan(tb[2]).all() and np.isnan(jac["dtb_dt"][2]).all()
+    assert np.isnan(tb[:2, 1]).all() and np.isnan(jac["dtb_de"][:2, 1]).all() and np.isfinite(jac["dtb_de"][:2, 0]).all()
 
 
 def test_argument_validation(gpu_ctx):
