@@ -1688,7 +1688,8 @@ __device__ __forceinline__ double lane_below(double v) {
 // One chunk of layer optical depths: lane = level holds tz[16] = its row's 16 frequencies = one 128-byte line, written
 // in eight 16-byte pieces.  (Transposing 4 x 4 blocks of pieces across each quad of lanes first, so that a store
 // instruction has every quad write 64 contiguous bytes, was measured: same-box A/B 3.93 vs 3.82 ms -- the 128 DPP
-// moves cost more than the fuller memory requests save; so were nontemporal stores: no difference.)
+// moves cost more than the fuller memory requests save; so were nontemporal stores: no difference; a fully coalesced
+// (level-fastest, i.e. wrong) layout as a timing experiment: 3.60 / 3.72 vs 3.74 / 3.75 ms -- the pattern is not the cost.)
 //   lev0 = level of lane 0 of this wave; a lane's row is stored when `row_ok(level, lane)` (duplicate / padding rows are not).
 template <class RowOk>
 __device__ __forceinline__ void store_tau_chunk(const double (&tz)[TAU_NFC], double* tau_prof /* + jbase */, int64_t fpitch,
