@@ -5,7 +5,8 @@ Random level counts (20..400), elevation sets (1..12 angles, 2..90 degrees, some
 perturbations (dry / saturated columns, cold stratospheres), for a wall-clock budget.  Prints the worst deviation and
 fails (exit 1) on anything above 1e-6 K or a validity-flag mismatch.
 
-    python tools/fuzz_parity.py [seconds] [seed] [opt]      (opt: also cloud liquid / ice and ray tracing, randomly)
+    python tools/fuzz_parity.py [seconds] [seed] [opt]      (opt: also cloud liquid / ice, ray tracing and ozone through a random
+                                                            synthetic line table, randomly; extras / wide / fine: see below)
     python tools/fuzz_parity.py calls=N [seed] [mode]       a fixed NUMBER of random calls instead of a time budget
                                                             (what the test suite runs: its coverage does not depend on the box)
 """
@@ -63,8 +64,19 @@ while time.time() < t_end and (max_calls is None or cases < max_calls):
     m = sp.get_model(name)
     a_in = ang.copy()
     if nan_k >= 0: a_in[nan_k] = np.nan
-    lwc = iwc = None
+    lwc = iwc = o3 = None
     rays = False
+    mname = name
+    if with_opt and rng.random() < 0.4:
+        # ozone mechanism: a random synthetic extra-species table (no real O3 list is bundled) + a random number-density profile
+        nx = int(rng.integers(1, 9))
+        fl = np.sort(rng.uniform(15.0, 200.0, nx))
+        if rng.random() < 0.5: fl[0] = float(rng.choice(frq)) + rng.normal(0, 0.02)      # a line on a channel
+        m = m.with_extra_lines(dict(fl=np.maximum(fl, 5.0), s1=10 ** rng.uniform(-13.5, -11.5, nx), b=rng.uniform(0.1, 3.0, nx),
+                                    w=rng.uniform(1.8e-3, 3.2e-3, nx), x=rng.uniform(0.5, 0.9, nx)), name=f"{name}_fuzzo3_{cases}")
+        mname = m
+        ppmv = np.where(P["z"] > rng.uniform(10, 20), rng.uniform(1, 10), rng.uniform(0.01, 0.3))
+        o3 = sp.number_density_from_ppmv(ppmv, P["p"], P["t"])
     if with_opt:
         if rng.random() < 0.7:
             lwc, iwc = np.zeros((nprof, nlev)), np.zeros((nprof, nlev))
@@ -77,7 +89,7 @@ while time.time() < t_end and (max_calls is None or cases < max_calls):
                     iwc[i, b:b + w] = rng.uniform(0.005, 0.1, len(iwc[i, b:b + w]))
         rays = bool(rng.random() < 0.6)
     if with_opt:
-        tb, valid = ctx.tb_batch(name, P["z"], P["p"], P["t"], P["rh"], frq, a_in, denliq=lwc, denice=iwc, ray_tracing=rays)
+        tb, valid = ctx.tb_batch(mname, P["z"], P["p"], P["t"], P["rh"], frq, a_in, denliq=lwc, denice=iwc, ray_tracing=rays, o3n=o3)
     elif extras:
         tb, valid, ex = ctx.tb_batch(name, P["z"], P["p"], P["t"], P["rh"], frq, a_in, extras=True)
     else:
@@ -87,7 +99,8 @@ while time.time() < t_end and (max_calls is None or cases < max_calls):
         try:
             if with_opt:
                 ref = co.tb_profile_opt(m, P["z"][i], P["p"][i], P["t"][i], P["rh"][i], frq, ang[good],
-                                        None if lwc is None else lwc[i], None if iwc is None else iwc[i], rays)["tbtotal"].reshape(good.sum(), len(frq))
+                                        None if lwc is None else lwc[i], None if iwc is None else iwc[i], rays,
+                                        None if o3 is None else o3[i])["tbtotal"].reshape(good.sum(), len(frq))
             else:
                 full = co.tb_profile(m, P["z"][i], P["p"][i], P["t"][i], P["rh"][i], frq, ang[good])
                 ref = full["tbtotal"].reshape(good.sum(), len(frq))
