@@ -370,8 +370,8 @@ int get_masks(mwrt_context* c, const mwrt_model* m, const double* frq, int nf, i
 // Chebyshev nodes of [flo, fhi] and the barycentric Lagrange weights of every target frequency of the window,
 // stored [chunk][node][target]; targets past the last frequency repeat it (their results are discarded)
 template <int NNODES>
-void window_nodes(const double* frq, int b, int e, double* fnode, double* blk_base) {
-  const int per = WIN_CHUNKS * WIN_NFC;
+void window_nodes(const double* frq, int b, int e, int nchunks, double* fnode, double* blk_base) {
+  const int per = nchunks * WIN_NFC;
   const double flo = frq[b], fhi = frq[e];
   long double x[NNODES], bw[NNODES];
   for (int m = 0; m < NNODES; ++m)
@@ -408,40 +408,73 @@ struct WindowSet {
   std::vector<double> lag, lag_h;       // [nwin][WIN_CHUNKS][nodes][WIN_NFC]
 };
 
+// far-line sets of a window [flo, fhi]: an O2 line is far beyond max(4 GHz, 1.6 half-spans), an H2O line beyond
+// max(30 GHz, 11.8 half-spans) -- the distance-to-half-span ratios the 16- and 8-node interpolations were sized for
+void window_far_sets(const mwrt_model_desc& t, double flo, double fhi, WinDesc* d) {
+  const double half = 0.5 * (fhi - flo);
+  const double mo = std::max(WIN_MARGIN_GHZ, 1.6 * half), mh = std::max(WIN_H2O_MARGIN_GHZ, 11.8 * half);
+  d->o2_far = 0; d->h2o_far_both = 0; d->h2o_far_res = 0;
+  for (int k = 0; k < t.n_o2; ++k) {
+    const double c = t.o2_f[k];
+    if (c < flo - mo || c > fhi + mo) d->o2_far |= 1ull << k;
+  }
+  for (int k = 0; k < t.n_h2o; ++k) {
+    const double c = t.h2o_fl[k];
+    if (!(c < flo - mh || c > fhi + mh)) continue;
+    // a speed-dependent line stays direct wherever its special shape (inside 10 half-widths) could reach the window
+    if (t.h2o_w2[k] > 0.0 && !(10.0 * sd_halfwidth_bound(t, k) < std::min(std::fabs(c - flo), std::fabs(c - fhi)) - 1.0)) continue;
+    const double g = WIN_CUTOFF_GUARD_GHZ;
+    const bool d1_in = std::fabs(flo - c) < 750.0 - g && std::fabs(fhi - c) < 750.0 - g;
+    const bool d2_in = fhi + c < 750.0 - g;
+    const bool d2_out = flo + c >= 750.0 + g;
+    if (d1_in && d2_in) d->h2o_far_both |= 1u << k;
+    else if (d1_in && d2_out) d->h2o_far_res |= 1u << k;
+    // anything else (a cutoff crossing the window, or both terms out) is left to the per-chunk loops
+  }
+}
+
 void build_windows(const mwrt_model_desc& t, const double* frq, int nf, WindowSet* ws) {
   const int per = WIN_CHUNKS * WIN_NFC;
   const int nchunks = (nf + WIN_NFC - 1) / WIN_NFC;
-  const int nwin = (nf + per - 1) / per;
+  const int nbase = (nf + per - 1) / per;
+  // base windows of WIN_CHUNKS chunks; two neighbours are MERGED (one node phase for both) when the merged window
+  // keeps every O2 line far and loses no H2O line from the far set: the out-of-band stretches of a spectrum
+  struct Span { int c0, nch; };
+  std::vector<Span> spans;
+  auto bounds = [&](const Span& sp, int* b, int* e) { *b = sp.c0 * WIN_NFC; *e = std::min(nf, (sp.c0 + sp.nch) * WIN_NFC) - 1; };
+  for (int w = 0; w < nbase; ++w) spans.push_back({w * WIN_CHUNKS, std::min(WIN_CHUNKS, nchunks - w * WIN_CHUNKS)});
+  const bool merge = std::getenv("MWRT_WIN_NOMERGE") == nullptr;                       // diagnostic: time the unmerged windows
+  for (size_t i = 0; i + 1 < spans.size();) {
+    const Span m{spans[i].c0, spans[i].nch + spans[i + 1].nch};
+    bool ok = merge && spans[i].nch == WIN_CHUNKS && m.nch <= WIN_CHUNKS_MAX;
+    if (ok) {
+      int b, e; bounds(m, &b, &e);
+      WinDesc dm{}, d0{}, d1{};
+      window_far_sets(t, frq[b], frq[e], &dm);
+      int b0, e0, b1, e1; bounds(spans[i], &b0, &e0); bounds(spans[i + 1], &b1, &e1);
+      window_far_sets(t, frq[b0], frq[e0], &d0);
+      window_far_sets(t, frq[b1], frq[e1], &d1);
+      const unsigned long long all_o2 = t.n_o2 >= 64 ? ~0ull : ((1ull << t.n_o2) - 1ull);
+      ok = dm.o2_far == all_o2 &&                                                     // no O2 line anywhere near
+           (dm.h2o_far_both | dm.h2o_far_res) == ((d0.h2o_far_both | d0.h2o_far_res) & (d1.h2o_far_both | d1.h2o_far_res));
+    }
+    if (ok) { spans[i] = m; spans.erase(spans.begin() + (long)i + 1); ++i; }           // (a merged window is not merged again)
+    else ++i;
+  }
+  const int nwin = (int)spans.size();
+  const int perm = WIN_CHUNKS_MAX * WIN_NFC;
   ws->wins.assign(nwin, WinDesc{});
-  ws->lag.assign((size_t)nwin * per * WIN_NODES, 0.0);
-  ws->lag_h.assign((size_t)nwin * per * WIN_NODES_H, 0.0);
+  ws->lag.assign((size_t)nwin * perm * WIN_NODES, 0.0);
+  ws->lag_h.assign((size_t)nwin * perm * WIN_NODES_H, 0.0);
   for (int w = 0; w < nwin; ++w) {
     WinDesc& d = ws->wins[w];
-    const int b = w * per, e = std::min(nf, b + per) - 1;
-    const double flo = frq[b], fhi = frq[e];
-    d.flo = flo; d.fhi = fhi;
-    d.first_chunk = w * WIN_CHUNKS;
-    d.nchunks = std::min(WIN_CHUNKS, nchunks - d.first_chunk);
-    window_nodes<WIN_NODES>(frq, b, e, d.fnode, ws->lag.data() + (size_t)w * per * WIN_NODES);
-    window_nodes<WIN_NODES_H>(frq, b, e, d.fnode_h, ws->lag_h.data() + (size_t)w * per * WIN_NODES_H);
-    // which lines are far from the whole window
-    for (int k = 0; k < t.n_o2; ++k) {
-      const double c = t.o2_f[k];
-      if (c < flo - WIN_MARGIN_GHZ || c > fhi + WIN_MARGIN_GHZ) d.o2_far |= 1ull << k;
-    }
-    for (int k = 0; k < t.n_h2o; ++k) {
-      const double c = t.h2o_fl[k];
-      if (!(c < flo - WIN_H2O_MARGIN_GHZ || c > fhi + WIN_H2O_MARGIN_GHZ)) continue;
-      // a speed-dependent line stays direct wherever its special shape (inside 10 half-widths) could reach the window
-      if (t.h2o_w2[k] > 0.0 && !(10.0 * sd_halfwidth_bound(t, k) < std::min(std::fabs(c - flo), std::fabs(c - fhi)) - 1.0)) continue;
-      const double g = WIN_CUTOFF_GUARD_GHZ;
-      const bool d1_in = std::fabs(flo - c) < 750.0 - g && std::fabs(fhi - c) < 750.0 - g;
-      const bool d2_in = fhi + c < 750.0 - g;
-      const bool d2_out = flo + c >= 750.0 + g;
-      if (d1_in && d2_in) d.h2o_far_both |= 1u << k;
-      else if (d1_in && d2_out) d.h2o_far_res |= 1u << k;
-      // anything else (a cutoff crossing the window, or both terms out) is left to the per-chunk loops
-    }
+    int b, e; bounds(spans[w], &b, &e);
+    d.flo = frq[b]; d.fhi = frq[e];
+    d.first_chunk = spans[w].c0;
+    d.nchunks = spans[w].nch;
+    window_nodes<WIN_NODES>(frq, b, e, d.nchunks, d.fnode, ws->lag.data() + (size_t)w * perm * WIN_NODES);
+    window_nodes<WIN_NODES_H>(frq, b, e, d.nchunks, d.fnode_h, ws->lag_h.data() + (size_t)w * perm * WIN_NODES_H);
+    window_far_sets(t, d.flo, d.fhi, &d);
   }
 }
 

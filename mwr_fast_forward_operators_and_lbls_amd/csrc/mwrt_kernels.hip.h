@@ -1841,7 +1841,8 @@ k_absorb(const AbsorbArgs A) {
 constexpr int WIN_NODES = 16;          // O2: lines from WIN_MARGIN_GHZ beyond the window
 constexpr int WIN_NODES_H = 8;         // H2O: lines from WIN_H2O_MARGIN_GHZ beyond it -- so smooth across the window that 8
                                        // nodes do (convergence ~ 25^-n); a third less LDS = a fourth workgroup per CU
-constexpr int WIN_CHUNKS = 8;
+constexpr int WIN_CHUNKS = 8;          // chunks of a base window
+constexpr int WIN_CHUNKS_MAX = 16;     // ... of a merged one (two neighbours with no line near either: one node phase for both)
 constexpr int WIN_NFC = 16;
 
 struct WinDesc {                       // one per window, built by the host (csrc/mwrt.hip: build_windows)
@@ -1859,8 +1860,8 @@ struct AbsorbWinArgs {
   const double* p; const double* t; const double* rh;
   const double* frq;
   const WinDesc* win;                  // [nwin]
-  const double* lagrange;              // [nwin][WIN_CHUNKS][WIN_NODES][WIN_NFC]: weight of node m for target j of chunk c
-  const double* lagrange_h;            // [nwin][WIN_CHUNKS][WIN_NODES_H][WIN_NFC]
+  const double* lagrange;              // [nwin][WIN_CHUNKS_MAX][WIN_NODES][WIN_NFC]: weight of node m for target j of chunk c
+  const double* lagrange_h;            // [nwin][WIN_CHUNKS_MAX][WIN_NODES_H][WIN_NFC]
   const LineMasks* masks;              // [nchunks of the list]: line_masks() of every chunk, precomputed (it depends on the
                                        // frequencies and the table only)
   double* awet; double* adry;
@@ -1880,8 +1881,8 @@ k_absorb_win(const AbsorbWinArgs A) {
   const cdoubles cfrq = (cdoubles)A.frq;
   typedef const __attribute__((address_space(4))) WinDesc* cwin;
   const cwin D = (cwin)(A.win + blockIdx.y);
-  const cdoubles Lw = (cdoubles)(A.lagrange + (size_t)blockIdx.y * WIN_CHUNKS * NFC * NN);
-  const cdoubles Lwh = (cdoubles)(A.lagrange_h + (size_t)blockIdx.y * WIN_CHUNKS * NFC * NH);
+  const cdoubles Lw = (cdoubles)(A.lagrange + (size_t)blockIdx.y * WIN_CHUNKS_MAX * NFC * NN);
+  const cdoubles Lwh = (cdoubles)(A.lagrange_h + (size_t)blockIdx.y * WIN_CHUNKS_MAX * NFC * NH);
   __shared__ double sfn[3 * NFC + 2];                        // the nodes, laid out like a chunk
   __shared__ double sfn_h[3 * NH + 2];                       // the H2O nodes
   __shared__ double sfq_w[MAXT / WAVE][3 * NFC + 2];         // the current chunk, one copy per wave (fill_chunk_table)
