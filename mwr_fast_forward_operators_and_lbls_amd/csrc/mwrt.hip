@@ -321,6 +321,14 @@ bool windows_eligible(const double* frq, int nf) {
   return true;
 }
 
+// upper bound of a speed-dependent H2O line's half width anywhere in an atmosphere (dry air <= 1100 hPa, vapour
+// <= 150 hPa, T >= 148 K): the host may put such a line in a window's far set only where 10 half-widths cannot
+// reach the window; the kernel re-checks per level and takes the line back if they can
+double sd_halfwidth_bound(const mwrt_model_desc& t, int k) {
+  return t.h2o_w0[k] * 1100.0 * std::pow(2.0, std::max(t.h2o_x[k], 0.0)) +
+         t.h2o_w0s[k] * 150.0 * std::pow(2.0, std::max(t.h2o_xs[k], 0.0));
+}
+
 // line_masks of every chunk of `nfc` frequencies (what the kernels' line loops are steered by; mwrt_kernels.hip.h LineMasks)
 void chunk_masks(const mwrt_model_desc& t, const double* frq, int nf, int nfc, std::vector<LineMasks>* out) {
   const int nchunks = (nf + nfc - 1) / nfc;
@@ -339,7 +347,10 @@ void chunk_masks(const mwrt_model_desc& t, const double* frq, int nf, int nfc, s
       if (dmin >= FAR_H2O_GHZ) lm.h2o_far |= 1u << k;
       if (dmin >= 750.0 + FAR_H2O_GHZ && smin >= 750.0 + FAR_H2O_GHZ) lm.h2o_none |= 1u << k;
       if (smin >= 750.0 + FAR_H2O_GHZ) lm.h2o_res |= 1u << k;
-      if (t.h2o_w2[k] > 0.0) lm.h2o_sd |= 1u << k;
+      if (t.h2o_w2[k] > 0.0) {
+        lm.h2o_sd |= 1u << k;
+        if (10.0 * sd_halfwidth_bound(t, k) < dmin - 1.0) lm.h2o_sdfar |= 1u << k;       // its special shape cannot reach the chunk
+      }
     }
   }
 }
@@ -393,14 +404,6 @@ void window_nodes(const double* frq, int b, int e, int nchunks, double* fnode, d
     for (int m = 0; m < NNODES; ++m) { q[m] = bw[m] / (f - x[m]); sum += q[m]; }
     for (int m = 0; m < NNODES; ++m) blk[m * WIN_NFC + j] = (double)(q[m] / sum);
   }
-}
-
-// upper bound of a speed-dependent H2O line's half width anywhere in an atmosphere (dry air <= 1100 hPa, vapour
-// <= 150 hPa, T >= 148 K): the host may put such a line in a window's far set only where 10 half-widths cannot
-// reach the window; the kernel re-checks per level and takes the line back if they can
-double sd_halfwidth_bound(const mwrt_model_desc& t, int k) {
-  return t.h2o_w0[k] * 1100.0 * std::pow(2.0, std::max(t.h2o_x[k], 0.0)) +
-         t.h2o_w0s[k] * 150.0 * std::pow(2.0, std::max(t.h2o_xs[k], 0.0));
 }
 
 struct WindowSet {

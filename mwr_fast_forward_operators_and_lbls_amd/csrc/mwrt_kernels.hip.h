@@ -244,6 +244,9 @@ struct LineMasks {
   unsigned h2o_none;           // both Lorentz terms beyond the 750-GHz cutoff for every frequency (FAR_H2O_GHZ margin)
   unsigned h2o_res;            // negative-frequency term beyond the cutoff for every frequency (e.g. 752 GHz from 22 GHz)
   unsigned h2o_sd;             // speed-dependent lines (W2 > 0)
+  unsigned h2o_sdfar;          // ... of those, the ones whose special shape (inside 10 half-widths) cannot reach any frequency of
+                               // the chunk by the host's bound: treated as plain lines, re-checked per level (wave vote)
+  unsigned pad_;
 };
 
 // The sets depend on the chunk's frequencies and the table only: the host computes them once per (model, frequency
@@ -254,6 +257,7 @@ __device__ __forceinline__ LineMasks load_masks(const LineMasks* table, int chun
   const cmasks q = (cmasks)table + chunk;
   LineMasks lm;
   lm.o2_far = q->o2_far; lm.h2o_far = q->h2o_far; lm.h2o_none = q->h2o_none; lm.h2o_res = q->h2o_res; lm.h2o_sd = q->h2o_sd;
+  lm.h2o_sdfar = q->h2o_sdfar; lm.pad_ = 0u;
   return lm;
 }
 
@@ -496,8 +500,10 @@ __device__ __forceinline__ void h2o_absorb(cmodel M, const LevelState& L, const 
   // Lines whose two terms are beyond the cutoff for every frequency (e.g. 916 GHz from 22 GHz) are skipped.
   const double fmin = sfq[2 * NFC], fmax = sfq[2 * NFC + 1];
   double bsum = init_bsum;                                    // sum of (count * s * base), frequency independent
-  unsigned deferred = (~lm.h2o_far | lm.h2o_res) & ~lm.h2o_sd & ~lm.h2o_none & all;
-  const unsigned setA = (MWRT_ABLATE & 2) ? 0u : (lm.h2o_far & ~lm.h2o_res & ~lm.h2o_sd & ~lm.h2o_none & all);
+  const unsigned sd_eff = lm.h2o_sd & ~lm.h2o_sdfar;          // lines that go to the speed-dependent loop straight away
+  unsigned sd_extra = 0u;                                     // ... and the "out of reach" ones a level of this wave takes back
+  unsigned deferred = (~lm.h2o_far | lm.h2o_res) & ~sd_eff & ~lm.h2o_none & all;
+  const unsigned setA = (MWRT_ABLATE & 2) ? 0u : (lm.h2o_far & ~lm.h2o_res & ~sd_eff & ~lm.h2o_none & all);
   // loop A walks its lines FOUR at a time (far_quad_accumulate); the count mod 4 left over joins loop B
   const unsigned leftA = (unsigned)lowest_bits(setA, __builtin_popcount(setA) & 3);
   deferred |= leftA;
@@ -511,13 +517,14 @@ __device__ __forceinline__ void h2o_absorb(cmodel M, const LevelState& L, const 
     fl.Bc = cc * cc;
     double P = 2.0 * q.sw, bs = 2.0 * q.sbase;
     bool plain = d1_in && d2_in;
-    if constexpr (NODES) {
-      // a speed-dependent line may sit in the window-far set only where its special shape (inside 10 half-widths,
-      // ABH2O_SD) is out of reach of the whole window at this level
-      if (M->h2o_w2[k] > 0.0) plain = plain && (10.0 * q.w0 < ::fmin(fabs(q.c1 - fmin), fabs(q.c1 - fmax)));
-    }
-    if (!__all(plain)) {                                                         // cutoff not uniform: loop B's job
-      if constexpr (NODES) *failed |= 1u << k; else deferred |= 1u << k;
+    // a speed-dependent line is a plain line only where its special shape (inside 10 half-widths, ABH2O_SD) is out of
+    // reach of every frequency in [fmin, fmax] at this level
+    const bool sdline = M->h2o_w2[k] > 0.0;
+    const bool reach = sdline && !__all(10.0 * q.w0 < ::fmin(fabs(q.c1 - fmin), fabs(q.c1 - fmax)));
+    if (reach || !__all(plain)) {                                                // SD within reach / cutoff not uniform
+      if constexpr (NODES) *failed |= 1u << k;
+      else if (reach) sd_extra |= 1u << k;                                       // ... the speed-dependent loop's job
+      else deferred |= 1u << k;                                                  // ... loop B's job
       P = 0.0; bs = 0.0;
     }
     fl.P = P;
@@ -542,8 +549,10 @@ __device__ __forceinline__ void h2o_absorb(cmodel M, const LevelState& L, const 
     const bool d2_in = fmax + q.c1 < 750.0 && fmin + q.c1 > -750.0;
     const bool d2_out = fmin + q.c1 >= 750.0;
     if (__all(d1_out && d2_out)) continue;
-    if constexpr (NODES) {                                     // a speed-dependent line within reach of its special shape: not here
-      if (M->h2o_w2[k] > 0.0 && !__all(10.0 * q.w0 < ::fmin(fabs(q.c1 - fmin), fabs(q.c1 - fmax)))) { *failed |= 1u << k; continue; }
+    if (M->h2o_w2[k] > 0.0 && !__all(10.0 * q.w0 < ::fmin(fabs(q.c1 - fmin), fabs(q.c1 - fmax)))) {
+      // a speed-dependent line within reach of its special shape: not a plain line at this level
+      if constexpr (NODES) *failed |= 1u << k; else sd_extra |= 1u << k;
+      continue;
     }
     LDS_RELOAD_FENCE();
     if (__all(d1_in && d2_in)) {                               // next to a line centre: detunings formed directly
@@ -601,7 +610,7 @@ __device__ __forceinline__ void h2o_absorb(cmodel M, const LevelState& L, const 
   // shape      Xc = (w0 - 1.5 w2 + i (d1 + 1.5 delta2)) / (w2 - i delta2),
   //            SD = 2 (1 - sqrt(pi) Xrt w(i Xrt)) / (w2 - i delta2),   Xrt = sqrt(Xc)
   // instead of the Lorentzian; outside it, and for the second term, the plain cutoff Lorentzians.
-  const unsigned setC = (MWRT_ABLATE & 4) ? 0u : (lm.h2o_sd & all);
+  const unsigned setC = (MWRT_ABLATE & 4) ? 0u : ((sd_eff | sd_extra) & all);
   for (unsigned m = setC; m; m &= m - 1u) {
     const int k = __builtin_ctz(m);
     const H2OLine q = h2o_line(M, k, pda, pvap, ti, tiln, ti2, shifted);
@@ -1929,7 +1938,7 @@ k_absorb_win(const AbsorbWinArgs A) {
   unsigned long long failed_o = 0ull;
   {
     LineMasks ln;
-    ln.o2_far = wf_o2; ln.h2o_far = wf_both | wf_res; ln.h2o_res = wf_res; ln.h2o_none = 0u; ln.h2o_sd = 0u;
+    ln.o2_far = wf_o2; ln.h2o_far = wf_both | wf_res; ln.h2o_res = wf_res; ln.h2o_none = 0u; ln.h2o_sd = 0u; ln.h2o_sdfar = 0u; ln.pad_ = 0u;
     {
       double Sh[NH];
       h2o_absorb<NH, true>(M, L, sfn_h, ln, Sh, ~(wf_both | wf_res), nullptr, 0.0, &failed_h, &bsum_far);
