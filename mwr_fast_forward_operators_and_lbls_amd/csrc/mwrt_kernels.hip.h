@@ -178,6 +178,26 @@ __device__ __forceinline__ double ftanh_half_small(double x) {
   return p * x;
 }
 
+// ... and for |x| <= 1/64: exp to degree 6 (truncation 9e-18), tanh(x/2) through x^7 (next term 3e-21 relative). 7 + 5 VALU.
+constexpr double EXP_TINY_X = 0.015625;
+__device__ __forceinline__ double fexp_tiny(double x) {
+  double p = 1.3888888888888889e-03;                 // 1/6!
+  MWRT_FMA_SC(p, x, 8.3333333333333332e-03);         // 1/5!
+  MWRT_FMA_SC(p, x, 4.1666666666666664e-02);         // 1/4!
+  MWRT_FMA_SC(p, x, 1.6666666666666666e-01);         // 1/3!
+  p = __builtin_fma(p, x, 0.5);
+  p = __builtin_fma(p, x, 1.0);
+  return __builtin_fma(p, x, 1.0);
+}
+__device__ __forceinline__ double ftanh_half_tiny(double x) {
+  const double u = x * x;
+  double p = -4.2162698412698413e-04;                // -17/40320
+  MWRT_FMA_SC(p, u, 4.1666666666666666e-03);         // 1/240
+  MWRT_FMA_SC(p, u, -4.1666666666666664e-02);        // -1/24
+  p = __builtin_fma(p, u, 0.5);
+  return p * x;
+}
+
 // max over the 16 lanes of a DPP row (lanes 16k .. 16k+15), delivered to all of them: row_ror 8, 4, 2, 1.
 // Four VALU instructions, no LDS crossbar.
 __device__ __forceinline__ float row16_max(float m) {
@@ -2127,7 +2147,17 @@ k_rte_tau(const RteTauArgs A) {
           B[a] = __builtin_fma(__builtin_fma(bi, E, bprev) * T[a], th, B[a]);
           T[a] *= E;
         };
-        if (__all(!(fabs(tz) * am_max > EXP_SMALL_X))) {          // thin at the longest path: thin at all of them, one vote
+        if (__all(!(fabs(tz) * am_max > EXP_TINY_X))) {           // tiny at the longest path: the short series for every elevation
+          KEEP_BRANCH();
+#pragma unroll
+          for (int a = 0; a < NA; ++a) {
+            const double tl = tz * am[a];
+            const double E = fexp_tiny(-tl);
+            B[a] = __builtin_fma(__builtin_fma(bi, E, bprev) * T[a], ftanh_half_tiny(tl), B[a]);
+            T[a] *= E;
+          }
+        } else if (__all(!(fabs(tz) * am_max > EXP_SMALL_X))) {   // thin at the longest path: thin at all of them, one vote
+          KEEP_BRANCH();
 #pragma unroll
           for (int a = 0; a < NA; ++a) thin_step(a, tz * am[a]);
         } else {
