@@ -95,7 +95,7 @@ struct mwrt_context {
   ParamCache frq_cache, am_cache, elev_cache;
   // fine-grid absorption: window descriptors + Lagrange matrices per (model, frequency list), immutable like ParamCache
   int absorption_mode = 0;      // 0 auto, 1 direct, 2 windowed
-  struct WinEntry { uint64_t model_id; std::vector<double> frq; char* d_blob; size_t off_lag, off_lagh; int nwin; };
+  struct WinEntry { uint64_t model_id; std::vector<double> frq; char* d_blob; size_t off_lag, off_lagh, off_lagsd; int nwin; };
   std::vector<WinEntry> win_cache;
   // line classification of every frequency chunk (LineMasks), per (model, frequency list, chunk width): depends on the
   // frequencies and the table only, so the host computes it once instead of every workgroup voting on it
@@ -350,6 +350,11 @@ void chunk_masks(const mwrt_model_desc& t, const double* frq, int nf, int nfc, s
       if (t.h2o_w2[k] > 0.0) {
         lm.h2o_sd |= 1u << k;
         if (10.0 * sd_halfwidth_bound(t, k) < dmin - 1.0) lm.h2o_sdfar |= 1u << k;       // its special shape cannot reach the chunk
+        // half-sampled shape: a full 16-frequency chunk of increasing frequencies, >= 3 GHz and 5 spans from the centre
+        bool inc = nfc == 16 && j1 - j0 == 16;
+        for (int j = j0 + 1; inc && j < j1; ++j) inc = frq[j] > frq[j - 1];
+        static const bool no_half = std::getenv("MWRT_NO_SD_HALF") != nullptr;            // diagnostic: time the full sampling
+        if (inc && !no_half && dmin >= 3.0 && dmin >= 5.0 * (frq[j1 - 1] - frq[j0])) lm.h2o_sdint |= 1u << k;
       }
     }
   }
@@ -408,7 +413,8 @@ void window_nodes(const double* frq, int b, int e, int nchunks, double* fnode, d
 
 struct WindowSet {
   std::vector<WinDesc> wins;
-  std::vector<double> lag, lag_h;       // [nwin][WIN_CHUNKS][nodes][WIN_NFC]
+  std::vector<double> lag, lag_h;       // [nwin][WIN_CHUNKS_MAX][nodes][WIN_NFC]
+  std::vector<double> lag_sd;           // [nchunks][SD_TARGETS][SD_NODES]: odd slots of a chunk from slots 0, 2, ..., 14, 15
 };
 
 // far-line sets of a window [flo, fhi]: an O2 line is far beyond max(4 GHz, 1.6 half-spans), an H2O line beyond
@@ -464,6 +470,21 @@ void build_windows(const mwrt_model_desc& t, const double* frq, int nf, WindowSe
     if (ok) { spans[i] = m; spans.erase(spans.begin() + (long)i + 1); ++i; }           // (a merged window is not merged again)
     else ++i;
   }
+  // Lagrange weights of the half-sampled speed-dependent shape, per chunk (zero for a partial last chunk: never used)
+  ws->lag_sd.assign((size_t)nchunks * SD_TARGETS * SD_NODES, 0.0);
+  for (int ch = 0; ch < nchunks; ++ch) {
+    if ((ch + 1) * WIN_NFC > nf) continue;
+    const double* f = frq + (size_t)ch * WIN_NFC;
+    for (int i = 0; i < SD_TARGETS; ++i) {
+      const long double x = f[2 * i + 1];
+      for (int n = 0; n < SD_NODES; ++n) {
+        long double w = 1.0L;
+        for (int q = 0; q < SD_NODES; ++q)
+          if (q != n) w *= (x - (long double)f[sd_node_slot(q)]) / ((long double)f[sd_node_slot(n)] - (long double)f[sd_node_slot(q)]);
+        ws->lag_sd[((size_t)ch * SD_TARGETS + i) * SD_NODES + n] = (double)w;
+      }
+    }
+  }
   const int nwin = (int)spans.size();
   const int perm = WIN_CHUNKS_MAX * WIN_NFC;
   ws->wins.assign(nwin, WinDesc{});
@@ -481,13 +502,13 @@ void build_windows(const mwrt_model_desc& t, const double* frq, int nf, WindowSe
   }
 }
 
-struct WinPtrs { const WinDesc* win; const double* lag; const double* lag_h; const LineMasks* masks; int nwin; };   // masks: get_masks(.., WIN_NFC)
+struct WinPtrs { const WinDesc* win; const double* lag; const double* lag_h; const double* lag_sd; const LineMasks* masks; int nwin; };   // masks: get_masks(.., WIN_NFC)
 
 int get_windows(mwrt_context* c, const mwrt_model* m, const double* frq, int nf, WinPtrs* out) {
   for (auto& e : c->win_cache)
     if (e.model_id == m->id && (int)e.frq.size() == nf && std::memcmp(e.frq.data(), frq, sizeof(double) * nf) == 0) {
       *out = WinPtrs{(const WinDesc*)e.d_blob, (const double*)(e.d_blob + e.off_lag), (const double*)(e.d_blob + e.off_lagh),
-                     nullptr, e.nwin};
+                     (const double*)(e.d_blob + e.off_lagsd), nullptr, e.nwin};
       return get_masks(c, m, frq, nf, WIN_NFC, &out->masks);
     }
   if (c->win_cache.size() >= 16) {                      // bounded: drop the oldest entry behind a device-wide drain
@@ -498,14 +519,16 @@ int get_windows(mwrt_context* c, const mwrt_model* m, const double* frq, int nf,
   WindowSet ws;
   build_windows(m->h_desc, frq, nf, &ws);
   auto up = [](size_t x) { return (x + 255) & ~(size_t)255; };
-  mwrt_context::WinEntry e{m->id, std::vector<double>(frq, frq + nf), nullptr, 0, 0, (int)ws.wins.size()};
+  mwrt_context::WinEntry e{m->id, std::vector<double>(frq, frq + nf), nullptr, 0, 0, 0, (int)ws.wins.size()};
   e.off_lag = up(sizeof(WinDesc) * ws.wins.size());
   e.off_lagh = e.off_lag + up(sizeof(double) * ws.lag.size());
-  const size_t total = e.off_lagh + up(sizeof(double) * ws.lag_h.size());
+  e.off_lagsd = e.off_lagh + up(sizeof(double) * ws.lag_h.size());
+  const size_t total = e.off_lagsd + up(sizeof(double) * ws.lag_sd.size());
   std::vector<char> host(total, 0);
   std::memcpy(host.data(), ws.wins.data(), sizeof(WinDesc) * ws.wins.size());
   std::memcpy(host.data() + e.off_lag, ws.lag.data(), sizeof(double) * ws.lag.size());
   std::memcpy(host.data() + e.off_lagh, ws.lag_h.data(), sizeof(double) * ws.lag_h.size());
+  std::memcpy(host.data() + e.off_lagsd, ws.lag_sd.data(), sizeof(double) * ws.lag_sd.size());
   HIP_TRY(hipMalloc((void**)&e.d_blob, total));
   hipError_t err = hipMemcpyAsync(e.d_blob, host.data(), total, hipMemcpyHostToDevice, c->stream);
   if (err == hipSuccess) err = hipStreamSynchronize(c->stream);
@@ -513,7 +536,7 @@ int get_windows(mwrt_context* c, const mwrt_model* m, const double* frq, int nf,
   c->win_cache.push_back(std::move(e));
   const auto& k = c->win_cache.back();
   *out = WinPtrs{(const WinDesc*)k.d_blob, (const double*)(k.d_blob + k.off_lag), (const double*)(k.d_blob + k.off_lagh),
-                 nullptr, k.nwin};
+                 (const double*)(k.d_blob + k.off_lagsd), nullptr, k.nwin};
   return get_masks(c, m, frq, nf, WIN_NFC, &out->masks);
 }
 
@@ -560,7 +583,7 @@ int layer_tau_launch(mwrt_context* c, const mwrt_model* m, int64_t nprof, int nl
     int rc = get_windows(c, m, frq, nf, &wp); if (rc) return rc;
     AbsorbWinArgs w{};
     w.M = m->d_desc; w.p = d_p; w.t = d_t; w.rh = d_rh; w.frq = dev_frq;
-    w.win = wp.win; w.lagrange = wp.lag; w.lagrange_h = wp.lag_h; w.masks = wp.masks;
+    w.win = wp.win; w.lagrange = wp.lag; w.lagrange_h = wp.lag_h; w.masks = wp.masks; w.lag_sd = wp.lag_sd;
     w.nlev = nlev; w.nf = nf; w.T = T;
     timing_begin(c, st);
     hipError_t e = launch_absorb_win(w, dim3((unsigned)nprof, (unsigned)wp.nwin), dim3(threads), st, true);
@@ -1011,7 +1034,7 @@ int mwrt_absorption_batch_device(mwrt_context* c, const mwrt_model* m, int64_t n
     rc = get_windows(c, m, frq, nf, &wp); if (rc) return rc;
     AbsorbWinArgs w{};
     w.M = m->d_desc; w.p = d_p; w.t = d_t; w.rh = d_rh; w.frq = dev_frq;
-    w.win = wp.win; w.lagrange = wp.lag; w.lagrange_h = wp.lag_h; w.masks = wp.masks;
+    w.win = wp.win; w.lagrange = wp.lag; w.lagrange_h = wp.lag_h; w.masks = wp.masks; w.lag_sd = wp.lag_sd;
     w.awet = d_awet; w.adry = d_adry; w.nlev = nlev; w.nf = nf;
     timing_begin(c, st);
     hipError_t e = launch_absorb_win(w, dim3((unsigned)nprof, (unsigned)wp.nwin), dim3(wthreads), st, false);

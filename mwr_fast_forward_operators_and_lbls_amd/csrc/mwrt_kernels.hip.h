@@ -266,7 +266,7 @@ struct LineMasks {
   unsigned h2o_sd;             // speed-dependent lines (W2 > 0)
   unsigned h2o_sdfar;          // ... of those, the ones whose special shape (inside 10 half-widths) cannot reach any frequency of
                                // the chunk by the host's bound: treated as plain lines, re-checked per level (wave vote)
-  unsigned pad_;
+  unsigned h2o_sdint;          // speed-dependent lines far enough from the chunk (>= 3 GHz and 5 spans) for the half-sampled shape
 };
 
 // The sets depend on the chunk's frequencies and the table only: the host computes them once per (model, frequency
@@ -277,7 +277,7 @@ __device__ __forceinline__ LineMasks load_masks(const LineMasks* table, int chun
   const cmasks q = (cmasks)table + chunk;
   LineMasks lm;
   lm.o2_far = q->o2_far; lm.h2o_far = q->h2o_far; lm.h2o_none = q->h2o_none; lm.h2o_res = q->h2o_res; lm.h2o_sd = q->h2o_sd;
-  lm.h2o_sdfar = q->h2o_sdfar; lm.pad_ = 0u;
+  lm.h2o_sdfar = q->h2o_sdfar; lm.h2o_sdint = q->h2o_sdint;
   return lm;
 }
 
@@ -485,6 +485,15 @@ __device__ __forceinline__ unsigned long long lowest_bits(unsigned long long m, 
   return out;
 }
 
+// Half-sampled speed-dependent shape (16-frequency chunks of a fine grid, chunk >= 3 GHz and 5 spans from the line centre).
+// The SD resonant shape costs ~92 VALU per (level, frequency); its DIFFERENCE from the Lorentzian it replaces is small
+// (<= 2 % of it) and smooth across a chunk, so it is evaluated at 9 of the 16 frequencies (slots 0, 2, ..., 14 and 15) and
+// interpolated to the other 7 with host-computed Lagrange weights: error <= 4e-12 of the line's Lorentzian
+// (probe on the oracle's formulas), against the 1e-10 the windowed path works to.  Where a lane is inside 10
+// half-widths the odd slots then get Lorentzian + interpolated difference; outside, the plain Lorentzian as always.
+constexpr int SD_NODES = 9, SD_TARGETS = 7;
+__host__ __device__ constexpr int sd_node_slot(int n) { return n < 8 ? 2 * n : 15; }
+
 // Window mode (k_absorb_win, fine spectral grids).  The lines far from a whole WINDOW of chunks are summed at a few
 // Chebyshev nodes of the window (NODES = true: raw line sums out, no continuum, no SD lines; a line whose per-lane
 // vote fails is reported in *failed and left out) and interpolated to each chunk's frequencies; the chunk call then
@@ -493,7 +502,8 @@ template <int NFC, bool NODES = false>
 __device__ __forceinline__ void h2o_absorb(cmodel M, const LevelState& L, const double* sfq /*LDS: {f, f^2} per slot*/,
                                            const LineMasks& lm, double (&awet)[NFC], unsigned excl = 0u,
                                            const double* init_sum = nullptr, double init_bsum = 0.0,
-                                           unsigned* failed = nullptr, double* bsum_out = nullptr) {
+                                           unsigned* failed = nullptr, double* bsum_out = nullptr,
+                                           cdoubles sdw = nullptr /* [SD_TARGETS][SD_NODES] weights of this chunk, or null */) {
   const double t = L.t;
   const double pvap = fdiv(L.rho * t, M->h2o_pvap_div);
   const double pda = L.p - pvap;
@@ -643,6 +653,9 @@ __device__ __forceinline__ void h2o_absorb(cmodel M, const LevelState& L, const 
     // pass 1: the cutoff Lorentzians, the resonant one masked out where the SD shape takes over
     const bool d1_in = (q.c1 - fmin < 750.0) && (fmax - q.c1 < 750.0) && (q.c1 - fmin > -750.0);
     const bool d2_in = fmax + q.c1 < 750.0 && fmin + q.c1 > -750.0;
+    // half-sampled shape for this line and chunk?  (needs both Lorentz terms inside the cutoff: the common case)
+    bool half = false;
+    if constexpr (NFC == 16 && !NODES) half = sdw != nullptr && ((lm.h2o_sdint >> k) & 1u) && __all(d1_in && d2_in);
     if (__all(d1_in && d2_in)) {                                // both inside the cutoff everywhere (22 / 183 GHz lines)
       const double sbase2 = q.sbase + q.sbase;
 #pragma unroll
@@ -652,7 +665,8 @@ __device__ __forceinline__ void h2o_absorb(cmodel M, const LevelState& L, const 
         const double d2 = f + q.c1;
         const double D1 = __builtin_fma(d1, d1, q.wsq);
         const double D2 = __builtin_fma(d2, d2, q.wsq);
-        const bool inner = fabs(d1) < sdlim;
+        // (half-sampled: the odd slots keep their Lorentzian and get the interpolated difference in pass 2)
+        const bool inner = fabs(d1) < sdlim && !(half && (j & 1) && j != 15);
         const double den12 = D1 * D2;
         double r = __builtin_amdgcn_rcp(den12);
         r = __builtin_fma(r, __builtin_fma(-den12, r, 1.0), r);
@@ -680,18 +694,53 @@ __device__ __forceinline__ void h2o_absorb(cmodel M, const LevelState& L, const 
     // pass 2: the SD resonant shape, frequency by frequency, only where some lane of the wave is inside
     // 10 half-widths (the branch is wave-uniform, so nothing of one frequency interleaves with the next)
     LDS_RELOAD_FENCE();
+    auto sd_shape = [&](double d1) -> double {                  // Re SD at detuning d1
+      const cplx xc = cmul(cplx{xre, d1 + xim0}, iden2);
+      const cplx xrt = csqrt_principal(xc);
+      const cplx w = dcerror_upper(-xrt.im, xrt.re);
+      const cplx pxw = cmul(cplx{1.77245385090551603 * xrt.re, 1.77245385090551603 * xrt.im}, w);
+      return __builtin_fma(2.0 * (1.0 - pxw.re), iden2.re, 2.0 * pxw.im * iden2.im);      // Re((2 - 2 pxw) iden2)
+    };
+    bool done = false;
+    if constexpr (NFC == 16 && !NODES) {
+      if (half) {
+        done = true;
+        // the chunk lies on one side of the line: the closest frequency is one of its ends
+        const double dmin = ::fmin(fabs(sfq[0] - q.c1), fabs(sfq[2 * 15] - q.c1));
+        if (__any(dmin < sdlim)) {
+          double dn[SD_NODES];
 #pragma unroll
-    for (int j = 0; j < NFC; ++j) {
-      const double d1 = sfq[2 * j] - q.c1;
-      const bool inner = fabs(d1) < sdlim;
-      if (__any(inner)) {
-        const cplx xc = cmul(cplx{xre, d1 + xim0}, iden2);
-        const cplx xrt = csqrt_principal(xc);
-        const cplx w = dcerror_upper(-xrt.im, xrt.re);
-        const cplx pxw = cmul(cplx{1.77245385090551603 * xrt.re, 1.77245385090551603 * xrt.im}, w);
-        const cplx sd = cmul(cplx{2.0 * (1.0 - pxw.re), -2.0 * pxw.im}, iden2);
-        const double r1 = inner ? sd.re - q.base : 0.0;
-        sum[j] = __builtin_fma(q.s, r1, sum[j]);
+          for (int n = 0; n < SD_NODES; ++n) {
+            constexpr int dummy = 0; (void)dummy;
+            const int j = sd_node_slot(n);
+            const double d1 = sfq[2 * j] - q.c1;
+            const double sdre = sd_shape(d1);
+            const double lres = fdiv1(q.w0, __builtin_fma(d1, d1, q.wsq));     // the Lorentzian the shape replaces
+            dn[n] = sdre - lres;
+            const double r1 = (fabs(d1) < sdlim) ? sdre - q.base : 0.0;
+            sum[j] = __builtin_fma(q.s, r1, sum[j]);
+          }
+#pragma unroll
+          for (int i = 0; i < SD_TARGETS; ++i) {
+            const int j = 2 * i + 1;
+            double dl = 0.0;
+#pragma unroll
+            for (int n = 0; n < SD_NODES; ++n) dl = __builtin_fma(sdw[i * SD_NODES + n], dn[n], dl);
+            const bool inner = fabs(sfq[2 * j] - q.c1) < sdlim;
+            sum[j] = __builtin_fma(q.s, inner ? dl : 0.0, sum[j]);
+          }
+        }
+      }
+    }
+    if (!done) {
+#pragma unroll
+      for (int j = 0; j < NFC; ++j) {
+        const double d1 = sfq[2 * j] - q.c1;
+        const bool inner = fabs(d1) < sdlim;
+        if (__any(inner)) {
+          const double r1 = inner ? sd_shape(d1) - q.base : 0.0;
+          sum[j] = __builtin_fma(q.s, r1, sum[j]);
+        }
       }
     }
   }
@@ -1893,6 +1942,7 @@ struct AbsorbWinArgs {
   const double* lagrange_h;            // [nwin][WIN_CHUNKS_MAX][WIN_NODES_H][WIN_NFC]
   const LineMasks* masks;              // [nchunks of the list]: line_masks() of every chunk, precomputed (it depends on the
                                        // frequencies and the table only)
+  const double* lag_sd;                // [nchunks][SD_TARGETS][SD_NODES]: the half-sampled SD shape's weights per chunk
   double* awet; double* adry;
   int nlev, nf;
   TauOut T;                            // TAU instantiations only
@@ -1958,7 +2008,7 @@ k_absorb_win(const AbsorbWinArgs A) {
   unsigned long long failed_o = 0ull;
   {
     LineMasks ln;
-    ln.o2_far = wf_o2; ln.h2o_far = wf_both | wf_res; ln.h2o_res = wf_res; ln.h2o_none = 0u; ln.h2o_sd = 0u; ln.h2o_sdfar = 0u; ln.pad_ = 0u;
+    ln.o2_far = wf_o2; ln.h2o_far = wf_both | wf_res; ln.h2o_res = wf_res; ln.h2o_none = 0u; ln.h2o_sd = 0u; ln.h2o_sdfar = 0u; ln.h2o_sdint = 0u;
     {
       double Sh[NH];
       h2o_absorb<NH, true>(M, L, sfn_h, ln, Sh, ~(wf_both | wf_res), nullptr, 0.0, &failed_h, &bsum_far);
@@ -2009,7 +2059,8 @@ k_absorb_win(const AbsorbWinArgs A) {
     double init[NFC], awet[NFC], adry[NFC];
     if constexpr (!TAU) {
       interpolate(Sh_l, Lth, NH, init);
-      h2o_absorb<NFC>(M, Lc, sfq, lm, awet, excl_h, init, bsum_far);
+      h2o_absorb<NFC>(M, Lc, sfq, lm, awet, excl_h, init, bsum_far, nullptr, nullptr,
+                      (cdoubles)(A.lag_sd + (size_t)(D->first_chunk + c) * SD_TARGETS * SD_NODES));
       if (active) {
 #pragma unroll
         for (int j = 0; j < NFC; ++j)
@@ -2038,7 +2089,8 @@ k_absorb_win(const AbsorbWinArgs A) {
         }
       };
       interpolate(Sh_l, Lth, NH, init);
-      h2o_absorb<NFC>(M, Lc, sfq, lm, awet, excl_h, init, bsum_far);
+      h2o_absorb<NFC>(M, Lc, sfq, lm, awet, excl_h, init, bsum_far, nullptr, nullptr,
+                      (cdoubles)(A.lag_sd + (size_t)(D->first_chunk + c) * SD_TARGETS * SD_NODES));
       layer_rows(awet);
       interpolate(So_l, Lt, NN, init);
       dry_absorb<NFC>(M, Lc, sfq, lm, adry, excl_o, init);
