@@ -913,6 +913,25 @@ __device__ __forceinline__ double s_over_atanh(double z) {
   return __builtin_fma(q, z, 1.0);
 }
 
+// The same quotient on the next band, |s| <= LOGMEAN_MID_S (adjacent absorptions up to 4 : 1, the coarse top of a
+// sounding): a (5,5) rational fit in z = s^2 on Chebyshev nodes of [0, 0.36], 7.7e-17 relative in exact arithmetic.
+// Ten FMAs and one division, about half of log_mean_any.
+constexpr double LOGMEAN_MID_S = 0.6;
+__device__ __forceinline__ double s_over_atanh_mid(double z) {
+  double pn = -1.24405457430790653678e-02, qd = -1.87173749238921052448e-03;
+  MWRT_FMA_SC(pn, z, 2.32467124128396325363e-01);
+  MWRT_FMA_SC(qd, z, 9.09554662683649162425e-02);
+  MWRT_FMA_SC(pn, z, -1.25179985749945586930e+00);
+  MWRT_FMA_SC(qd, z, -7.29233489586724676923e-01);
+  MWRT_FMA_SC(pn, z, 2.79764691392900100515e+00);
+  MWRT_FMA_SC(qd, z, 2.07624733687436672750e+00);
+  MWRT_FMA_SC(pn, z, -2.76419873116542634427e+00);
+  MWRT_FMA_SC(qd, z, -2.43086539783209769889e+00);
+  pn = __builtin_fma(pn, z, 1.0);
+  qd = __builtin_fma(qd, z, 1.0);
+  return fdiv1(pn, qd);
+}
+
 // The log-mean for ANY ratio of two positive values with one division for the logarithm and one for the quotient:
 //   x1/x0 = 2^e m,  m in [1/sqrt 2, sqrt 2]  (e from the exponent fields, x0' = x0 2^e),
 //   s' = (x1 - x0')/(x1 + x0'),  ln(x1/x0) = e ln 2 + 2 s' (atanh(s')/s'),  result = (x1 - x0) / ln(x1/x0).
@@ -958,6 +977,9 @@ __device__ __forceinline__ double layer_value(double x1, double x0, bool& neg, b
   if (__all(!live || special || fabs(s) <= LOGMEAN_SMALL_S)) {
     KEEP_BRANCH();
     r = (0.5 * sm) * s_over_atanh(s * s);
+  } else if (__all(!live || special || fabs(s) <= LOGMEAN_MID_S)) {
+    KEEP_BRANCH();
+    r = (0.5 * sm) * s_over_atanh_mid(s * s);
   } else {
     KEEP_BRANCH();
     r = log_mean_any(x1, x0, d);
@@ -978,7 +1000,7 @@ __device__ __forceinline__ double layer_value(double x1, double x0, bool& neg, b
 template <bool ZEROFLG = true>
 __device__ __forceinline__ void layer_value4(double (&x1)[4], const double (&x0)[4], bool& neg, bool live) {
   double s[4];
-  bool small = true, special = false;
+  bool small = true, mid = true, special = false;
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
     const double d = x1[k] - x0[k];
@@ -986,6 +1008,7 @@ __device__ __forceinline__ void layer_value4(double (&x1)[4], const double (&x0)
     s[k] = fdiv1(d, x1[k] + x0[k]);
     special = special || sp;
     small = small && (sp || fabs(s[k]) <= LOGMEAN_SMALL_S);
+    mid = mid && (sp || fabs(s[k]) <= LOGMEAN_MID_S);
   }
   special = special && live;
   double r[4];
@@ -993,6 +1016,10 @@ __device__ __forceinline__ void layer_value4(double (&x1)[4], const double (&x0)
     KEEP_BRANCH();
 #pragma unroll
     for (int k = 0; k < 4; ++k) r[k] = (0.5 * (x1[k] + x0[k])) * s_over_atanh(s[k] * s[k]);
+  } else if (__all(!live || mid)) {
+    KEEP_BRANCH();
+#pragma unroll
+    for (int k = 0; k < 4; ++k) r[k] = (0.5 * (x1[k] + x0[k])) * s_over_atanh_mid(s[k] * s[k]);
   } else {
     KEEP_BRANCH();
 #pragma unroll
