@@ -336,15 +336,31 @@ void chunk_masks(const mwrt_model_desc& t, const double* frq, int nf, int nfc, s
   for (int ch = 0; ch < nchunks; ++ch) {
     const int j0 = ch * nfc, j1 = std::min(nf, j0 + nfc);
     LineMasks& lm = (*out)[ch];
+    // very far lines (vfar_add): poles of the line's term in u = f^2, u ~ c^2 -+ 2 i c w, at >= 1/VF_RATIO_MAX half ranges
+    // from the middle of the chunk's f^2 values -- with 2 GHz of allowance for pressure shifts and 10 GHz for the half width
+    double ulo = 1e300, uhi = 0.0;
+    for (int j = j0; j < j1; ++j) { ulo = std::min(ulo, frq[j] * frq[j]); uhi = std::max(uhi, frq[j] * frq[j]); }
+    lm.vf_u0 = 0.5 * (ulo + uhi);
+    lm.vf_h = std::max(0.5 * (uhi - ulo), 1.0);
+    auto very_far = [&](double c) {
+      const double cl = std::max(c - 2.0, 0.0), ch = c + 2.0;
+      const double plo = cl * cl - 100.0, phi = ch * ch;             // real part of the poles lies in [plo, phi]
+      const double dist = (lm.vf_u0 < plo) ? plo - lm.vf_u0 : ((lm.vf_u0 > phi) ? lm.vf_u0 - phi : 0.0);
+      return lm.vf_h <= VF_RATIO_MAX * dist;
+    };
+    static const bool no_vfar = std::getenv("MWRT_NO_VFAR") != nullptr;                   // diagnostic: time the direct sums
     for (int k = 0; k < t.n_o2; ++k) {
       double dmin = 1e300;
       for (int j = j0; j < j1; ++j) dmin = std::min(dmin, std::fabs(frq[j] - t.o2_f[k]));
       if (dmin >= FAR_MIN_GHZ + FAR_SHIFT_GHZ) lm.o2_far |= 1ull << k;
+      if (!no_vfar && very_far(t.o2_f[k])) lm.o2_vfar |= 1ull << k;
     }
+    if (__builtin_popcountll(lm.o2_vfar) < VF_MIN_LINES) lm.o2_vfar = 0;
     for (int k = 0; k < t.n_h2o; ++k) {
       double dmin = 1e300, smin = 1e300;
       for (int j = j0; j < j1; ++j) { dmin = std::min(dmin, std::fabs(frq[j] - t.h2o_fl[k])); smin = std::min(smin, std::fabs(frq[j] + t.h2o_fl[k])); }
       if (dmin >= FAR_H2O_GHZ) lm.h2o_far |= 1u << k;
+      if (!no_vfar && very_far(t.h2o_fl[k])) lm.h2o_vfar |= 1u << k;
       if (dmin >= 750.0 + FAR_H2O_GHZ && smin >= 750.0 + FAR_H2O_GHZ) lm.h2o_none |= 1u << k;
       if (smin >= 750.0 + FAR_H2O_GHZ) lm.h2o_res |= 1u << k;
       if (t.h2o_w2[k] > 0.0) {
@@ -357,6 +373,7 @@ void chunk_masks(const mwrt_model_desc& t, const double* frq, int nf, int nfc, s
         if (inc && !no_half && dmin >= 3.0 && dmin >= 5.0 * (frq[j1 - 1] - frq[j0])) lm.h2o_sdint |= 1u << k;
       }
     }
+    if (__builtin_popcount(lm.h2o_vfar) < VF_MIN_LINES) lm.h2o_vfar = 0;
   }
 }
 

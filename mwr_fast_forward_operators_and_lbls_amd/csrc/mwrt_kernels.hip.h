@@ -267,6 +267,9 @@ struct LineMasks {
   unsigned h2o_sdfar;          // ... of those, the ones whose special shape (inside 10 half-widths) cannot reach any frequency of
                                // the chunk by the host's bound: treated as plain lines, re-checked per level (wave vote)
   unsigned h2o_sdint;          // speed-dependent lines far enough from the chunk (>= 3 GHz and 5 spans) for the half-sampled shape
+  unsigned h2o_vfar;           // "very far" lines: summed as ONE Taylor polynomial in f^2 about the chunk's middle (vfar_add)
+  unsigned long long o2_vfar;
+  double vf_u0, vf_h;          // middle and half range of the chunk's f^2 values [GHz^2] (vf_h >= 1)
 };
 
 // The sets depend on the chunk's frequencies and the table only: the host computes them once per (model, frequency
@@ -278,6 +281,7 @@ __device__ __forceinline__ LineMasks load_masks(const LineMasks* table, int chun
   LineMasks lm;
   lm.o2_far = q->o2_far; lm.h2o_far = q->h2o_far; lm.h2o_none = q->h2o_none; lm.h2o_res = q->h2o_res; lm.h2o_sd = q->h2o_sd;
   lm.h2o_sdfar = q->h2o_sdfar; lm.h2o_sdint = q->h2o_sdint;
+  lm.h2o_vfar = q->h2o_vfar; lm.o2_vfar = q->o2_vfar; lm.vf_u0 = q->vf_u0; lm.vf_h = q->vf_h;
   return lm;
 }
 
@@ -478,6 +482,65 @@ __device__ __forceinline__ void far_quad_accumulate(const double* sfq, const Far
   }
 }
 
+// VERY far lines: a line whose poles in u = f^2 (u ~ c^2 -+ 2 i c w) lie at >= 1/VF_RATIO_MAX half ranges from the middle u0
+// of the chunk's f^2 values -- the submillimetre lines seen from a 22-58 GHz chunk -- is analytic across the chunk with
+// room to spare: its term (P u + Q)/(u^2 + A2 u + Bc) is expanded in x = (u - u0)/h, |x| <= 1,
+//   d(u) = d0 + d1 h x + h^2 x^2,   c_0 = n(u0)/d0,  c_1 = (P h - d1 h c_0)/d0,  c_j = -(d1 h c_{j-1} + h^2 c_{j-2})/d0,
+// and ALL such lines of a species share one polynomial: ~40 instructions per line instead of 7 per line and frequency, plus
+// one Horner evaluation per frequency.  Truncation after x^7: sum_{j>=8} (j+1) r^j <= 4e-14 of the line's own term at
+// r = VF_RATIO_MAX (the poles' distance ratio), and such a line is a few percent of the absorption at most; the host picks
+// the lines (chunk_masks) with the shift / width allowances.
+constexpr int VF_TERMS = 8;
+constexpr double VF_RATIO_MAX = 0.016;
+constexpr int VF_MIN_LINES = 4;              // fewer lines than this do not pay for the Horner pass (8 per frequency)
+__device__ __forceinline__ void vfar_add(const FarLine& fl, double u0, double h, double (&acc)[VF_TERMS]) {
+  const double d0 = __builtin_fma(u0, u0 + fl.A2, fl.Bc);
+  const double d1h = __builtin_fma(fl.A2, h, (2.0 * u0) * h);
+  double rd = __builtin_amdgcn_rcp(d0);
+  rd = __builtin_fma(rd, __builtin_fma(-d0, rd, 1.0), rd);
+  const double a = -d1h * rd, b = (-(h * h)) * rd;
+  double cm2 = __builtin_fma(fl.P, u0, fl.Q) * rd;
+  double cm1 = __builtin_fma(a, cm2, (fl.P * h) * rd);
+  acc[0] += cm2;
+  acc[1] += cm1;
+#pragma unroll
+  for (int j = 2; j < VF_TERMS; ++j) {
+    const double cj = __builtin_fma(a, cm1, b * cm2);
+    acc[j] += cj;
+    cm2 = cm1; cm1 = cj;
+  }
+}
+template <int NFC>
+__device__ __forceinline__ void vfar_eval(const double* sfq, double u0, double h, const double (&acc)[VF_TERMS], double (&sum)[NFC]) {
+  const double invh = 1.0 / h, mu = -u0 * invh;               // wave-uniform
+#pragma unroll
+  for (int j = 0; j < NFC; ++j) {
+    const double x = __builtin_fma(sfq[2 * j + 1], invh, mu);
+    double p = acc[VF_TERMS - 1];
+#pragma unroll
+    for (int k = VF_TERMS - 2; k >= 0; --k) p = __builtin_fma(p, x, acc[k]);
+    sum[j] += p;
+  }
+}
+
+// ... and TWO far lines through one reciprocal (what a quad loop leaves over, when it leaves two or three)
+template <int NFC>
+__device__ __forceinline__ void far_pair_accumulate(const double* sfq, const FarLine& a, const FarLine& b, double (&sum)[NFC]) {
+#pragma unroll
+  for (int j = 0; j < NFC; ++j) {
+    const double f2 = sfq[2 * j + 1];
+    const double d0 = __builtin_fma(f2, f2 + a.A2, a.Bc);
+    const double d1 = __builtin_fma(f2, f2 + b.A2, b.Bc);
+    const double n0 = __builtin_fma(f2, a.P, a.Q);
+    const double n1 = __builtin_fma(f2, b.P, b.Q);
+    const double den = d0 * d1;
+    const double num = __builtin_fma(n0, d1, n1 * d0);
+    double r = __builtin_amdgcn_rcp(den);
+    r = __builtin_fma(r, __builtin_fma(-den, r, 1.0), r);
+    sum[j] = __builtin_fma(num, r, sum[j]);
+  }
+}
+
 // lowest `n` set bits of `m` (n < 4): the lines a quad loop leaves to the general loop
 __device__ __forceinline__ unsigned long long lowest_bits(unsigned long long m, int n) {
   unsigned long long out = 0;
@@ -534,9 +597,13 @@ __device__ __forceinline__ void h2o_absorb(cmodel M, const LevelState& L, const 
   unsigned sd_extra = 0u;                                     // ... and the "out of reach" ones a level of this wave takes back
   unsigned deferred = (~lm.h2o_far | lm.h2o_res) & ~sd_eff & ~lm.h2o_none & all;
   const unsigned setA = (MWRT_ABLATE & 2) ? 0u : (lm.h2o_far & ~lm.h2o_res & ~sd_eff & ~lm.h2o_none & all);
-  // loop A walks its lines FOUR at a time (far_quad_accumulate); the count mod 4 left over joins loop B
-  const unsigned leftA = (unsigned)lowest_bits(setA, __builtin_popcount(setA) & 3);
-  deferred |= leftA;
+  // ... of which the very far ones go through one Taylor polynomial (vfar_add) and the rest
+  // FOUR at a time through far_quad_accumulate; the count mod 4 left over joins loop B
+  const unsigned setV = NODES ? 0u : (setA & lm.h2o_vfar);
+  const unsigned setQ = setA & ~setV;
+  const unsigned leftA = (unsigned)lowest_bits(setQ, __builtin_popcount(setQ) & 3);
+  const unsigned leftP = (__builtin_popcount(leftA) >= 2) ? (unsigned)lowest_bits(leftA, 2) : 0u;      // ... two of them as a pair
+  deferred |= leftA & ~leftP;
   auto far_setup = [&](int k, FarLine& fl) {
     const H2OLine q = h2o_line(M, k, pda, pvap, ti, tiln, ti2, shifted);
     const bool d1_in = (q.c1 - fmin < 750.0) && (fmax - q.c1 < 750.0) && (q.c1 - fmin > -750.0);
@@ -561,7 +628,19 @@ __device__ __forceinline__ void h2o_absorb(cmodel M, const LevelState& L, const 
     fl.Q = P * cc;
     bsum += bs;
   };
-  for (unsigned m = setA & ~leftA; m;) {
+  if (setV) {
+    double acc[VF_TERMS];
+#pragma unroll
+    for (int j = 0; j < VF_TERMS; ++j) acc[j] = 0.0;
+    for (unsigned m = setV; m; m &= m - 1u) {
+      FarLine q;
+      far_setup(__builtin_ctz(m), q);
+      vfar_add(q, lm.vf_u0, lm.vf_h, acc);
+    }
+    LDS_RELOAD_FENCE();
+    vfar_eval<NFC>(sfq, lm.vf_u0, lm.vf_h, acc, sum);
+  }
+  for (unsigned m = setQ & ~leftA; m;) {
     FarLine q0, q1, q2, q3;
     far_setup(__builtin_ctz(m), q0); m &= m - 1u;
     far_setup(__builtin_ctz(m), q1); m &= m - 1u;
@@ -569,6 +648,14 @@ __device__ __forceinline__ void h2o_absorb(cmodel M, const LevelState& L, const 
     far_setup(__builtin_ctz(m), q3); m &= m - 1u;
     LDS_RELOAD_FENCE();
     far_quad_accumulate<NFC>(sfq, q0, q1, q2, q3, sum);
+  }
+  if (leftP) {
+    FarLine q0, q1;
+    unsigned m = leftP;
+    far_setup(__builtin_ctz(m), q0); m &= m - 1u;
+    far_setup(__builtin_ctz(m), q1);
+    LDS_RELOAD_FENCE();
+    far_pair_accumulate<NFC>(sfq, q0, q1, sum);
   }
   if (MWRT_ABLATE & 2) deferred = 0u;
   for (unsigned m = deferred; m; m &= m - 1u) {
@@ -825,8 +912,11 @@ __device__ __forceinline__ void dry_absorb(cmodel M, const LevelState& L, const 
   unsigned long long near = ~lm.o2_far & all;
   const unsigned long long setA = (MWRT_ABLATE & 1) ? 0ull : (lm.o2_far & all);
   // ... four lines at a time (far_quad_accumulate); the count mod 4 left over joins loop B
-  const unsigned long long leftA = lowest_bits(setA, __builtin_popcountll(setA) & 3);
-  near |= leftA;
+  const unsigned long long setV = NODES ? 0ull : (setA & lm.o2_vfar);      // very far lines: one Taylor polynomial (vfar_add)
+  const unsigned long long setQ = setA & ~setV;
+  const unsigned long long leftA = lowest_bits(setQ, __builtin_popcountll(setQ) & 3);
+  const unsigned long long leftP = (__builtin_popcountll(leftA) >= 2) ? lowest_bits(leftA, 2) : 0ull;   // ... two of them as a pair
+  near |= leftA & ~leftP;
   auto far_setup = [&](int k, FarLine& fl) {
     const O2Line q = line_setup(k);
     double P = q.P, Q = q.Q;
@@ -835,7 +925,19 @@ __device__ __forceinline__ void dry_absorb(cmodel M, const LevelState& L, const 
     fl.A2 = 2.0 * __builtin_fma(-q.c1, q.c1, q.df2);
     fl.Bc = q.cc * q.cc;
   };
-  for (unsigned long long m = setA & ~leftA; m;) {
+  if (setV) {
+    double acc[VF_TERMS];
+#pragma unroll
+    for (int j = 0; j < VF_TERMS; ++j) acc[j] = 0.0;
+    for (unsigned long long m = setV; m; m &= m - 1ull) {
+      FarLine q;
+      far_setup(__builtin_ctzll(m), q);
+      vfar_add(q, lm.vf_u0, lm.vf_h, acc);
+    }
+    LDS_RELOAD_FENCE();
+    vfar_eval<NFC>(sfq, lm.vf_u0, lm.vf_h, acc, sum);
+  }
+  for (unsigned long long m = setQ & ~leftA; m;) {
     FarLine q0, q1, q2, q3;
     far_setup(__builtin_ctzll(m), q0); m &= m - 1ull;
     far_setup(__builtin_ctzll(m), q1); m &= m - 1ull;
@@ -843,6 +945,14 @@ __device__ __forceinline__ void dry_absorb(cmodel M, const LevelState& L, const 
     far_setup(__builtin_ctzll(m), q3); m &= m - 1ull;
     LDS_RELOAD_FENCE();
     far_quad_accumulate<NFC>(sfq, q0, q1, q2, q3, sum);
+  }
+  if (leftP) {
+    FarLine q0, q1;
+    unsigned long long m = leftP;
+    far_setup(__builtin_ctzll(m), q0); m &= m - 1ull;
+    far_setup(__builtin_ctzll(m), q1);
+    LDS_RELOAD_FENCE();
+    far_pair_accumulate<NFC>(sfq, q0, q1, sum);
   }
   // loop B: lines next to a chunk frequency -- D1, D2 formed from the detunings directly (no cancellation)
   if (MWRT_ABLATE & 1) near = 0ull;
