@@ -198,6 +198,16 @@ __device__ __forceinline__ double ftanh_half_tiny(double x) {
   return p * x;
 }
 
+// Wave votes straight from the comparison mask: HIP's __all / __any take an int, and the compiler materialises it
+// (v_cndmask 0/1, v_cmp_ne) before comparing with exec -- two VALU instructions and a VALU -> SALU hazard per vote.
+typedef unsigned long long wmask;
+__device__ __forceinline__ bool wave_all(bool p) { return __builtin_amdgcn_ballot_w64(!p) == 0ull; }
+__device__ __forceinline__ bool wave_any(bool p) { return __builtin_amdgcn_ballot_w64(p) != 0ull; }
+// ... and a conjunction of comparisons as the AND of their masks on the scalar unit (pass each comparison separately)
+__device__ __forceinline__ wmask wballot(bool p) { return __builtin_amdgcn_ballot_w64(p); }
+template <class... B>
+__device__ __forceinline__ bool wave_all_of(B... b) { return (wballot(b) & ...) == wballot(true); }
+
 // max over the 16 lanes of a DPP row (lanes 16k .. 16k+15), delivered to all of them: row_ror 8, 4, 2, 1.
 // Four VALU instructions, no LDS crossbar.
 __device__ __forceinline__ float row16_max(float m) {
@@ -216,7 +226,7 @@ constexpr int K2_SORT_MIN_SEGLEN = 16;     // shorter segments: dealing the item
 // cancellation of exp(x) - 1 (which costs pyrtlib itself ~3e-14 relative; far below the parity bar).
 constexpr double PLANCK_SMALL_X = 0.03125;
 __device__ __forceinline__ double planck_b(double x, double inv_x) {
-  if (__all(x <= PLANCK_SMALL_X && x > 0.0)) {
+  if (wave_all_of(x <= PLANCK_SMALL_X, x > 0.0)) {
     const double u = x * x;
     double g = 3.3068783068783071e-05;                 // 1/30240
     MWRT_FMA_SC(g, u, -1.3888888888888889e-03);        // -1/720
@@ -606,19 +616,18 @@ __device__ __forceinline__ void h2o_absorb(cmodel M, const LevelState& L, const 
   deferred |= leftA & ~leftP;
   auto far_setup = [&](int k, FarLine& fl) {
     const H2OLine q = h2o_line(M, k, pda, pvap, ti, tiln, ti2, shifted);
-    const bool d1_in = (q.c1 - fmin < 750.0) && (fmax - q.c1 < 750.0) && (q.c1 - fmin > -750.0);
-    const bool d2_in = fmax + q.c1 < 750.0 && fmin + q.c1 > -750.0;
+    // both terms inside the cutoff for every lane?
+    const bool plain = wave_all_of(q.c1 - fmin < 750.0, fmax - q.c1 < 750.0, q.c1 - fmin > -750.0, fmax + q.c1 < 750.0, fmin + q.c1 > -750.0);
     // both terms in:  s w (D1 + D2)/(D1 D2) - 2 s base,  D1 + D2 = 2 f^2 + 2 (c^2 + w^2)
     const double cc = __builtin_fma(q.c1, q.c1, q.wsq);
     fl.A2 = 2.0 * __builtin_fma(-q.c1, q.c1, q.wsq);
     fl.Bc = cc * cc;
     double P = 2.0 * q.sw, bs = 2.0 * q.sbase;
-    bool plain = d1_in && d2_in;
     // a speed-dependent line is a plain line only where its special shape (inside 10 half-widths, ABH2O_SD) is out of
     // reach of every frequency in [fmin, fmax] at this level
     const bool sdline = M->h2o_w2[k] > 0.0;
-    const bool reach = sdline && !__all(10.0 * q.w0 < ::fmin(fabs(q.c1 - fmin), fabs(q.c1 - fmax)));
-    if (reach || !__all(plain)) {                                                // SD within reach / cutoff not uniform
+    const bool reach = sdline && !wave_all(10.0 * q.w0 < ::fmin(fabs(q.c1 - fmin), fabs(q.c1 - fmax)));
+    if (reach || !plain) {                                                // SD within reach / cutoff not uniform
       if constexpr (NODES) *failed |= 1u << k;
       else if (reach) sd_extra |= 1u << k;                                       // ... the speed-dependent loop's job
       else deferred |= 1u << k;                                                  // ... loop B's job
@@ -665,14 +674,14 @@ __device__ __forceinline__ void h2o_absorb(cmodel M, const LevelState& L, const 
     const bool d1_out = (q.c1 - fmax >= 750.0) || (fmin - q.c1 >= 750.0);
     const bool d2_in = fmax + q.c1 < 750.0 && fmin + q.c1 > -750.0;
     const bool d2_out = fmin + q.c1 >= 750.0;
-    if (__all(d1_out && d2_out)) continue;
-    if (M->h2o_w2[k] > 0.0 && !__all(10.0 * q.w0 < ::fmin(fabs(q.c1 - fmin), fabs(q.c1 - fmax)))) {
+    if (wave_all(d1_out && d2_out)) continue;
+    if (M->h2o_w2[k] > 0.0 && !wave_all(10.0 * q.w0 < ::fmin(fabs(q.c1 - fmin), fabs(q.c1 - fmax)))) {
       // a speed-dependent line within reach of its special shape: not a plain line at this level
       if constexpr (NODES) *failed |= 1u << k; else sd_extra |= 1u << k;
       continue;
     }
     LDS_RELOAD_FENCE();
-    if (__all(d1_in && d2_in)) {                               // next to a line centre: detunings formed directly
+    if (wave_all(d1_in && d2_in)) {                               // next to a line centre: detunings formed directly
       bsum = __builtin_fma(2.0, q.sbase, bsum);
 #pragma unroll
       for (int j = 0; j < NFC; ++j) {
@@ -686,7 +695,7 @@ __device__ __forceinline__ void h2o_absorb(cmodel M, const LevelState& L, const 
         r = __builtin_fma(r, __builtin_fma(-den12, r, 1.0), r);
         sum[j] = __builtin_fma((D1 + D2) * r, q.sw, sum[j]);
       }
-    } else if (__all(d1_in && d2_out)) {                       // resonant term only (e.g. 752 GHz seen from 22 GHz)
+    } else if (wave_all(d1_in && d2_out)) {                       // resonant term only (e.g. 752 GHz seen from 22 GHz)
       bsum += q.sbase;
 #pragma unroll
       for (int j = 0; j < NFC; ++j) {
@@ -742,8 +751,8 @@ __device__ __forceinline__ void h2o_absorb(cmodel M, const LevelState& L, const 
     const bool d2_in = fmax + q.c1 < 750.0 && fmin + q.c1 > -750.0;
     // half-sampled shape for this line and chunk?  (needs both Lorentz terms inside the cutoff: the common case)
     bool half = false;
-    if constexpr (NFC == 16 && !NODES) half = sdw != nullptr && ((lm.h2o_sdint >> k) & 1u) && __all(d1_in && d2_in);
-    if (__all(d1_in && d2_in)) {                                // both inside the cutoff everywhere (22 / 183 GHz lines)
+    if constexpr (NFC == 16 && !NODES) half = sdw != nullptr && ((lm.h2o_sdint >> k) & 1u) && wave_all(d1_in && d2_in);
+    if (wave_all(d1_in && d2_in)) {                                // both inside the cutoff everywhere (22 / 183 GHz lines)
       const double sbase2 = q.sbase + q.sbase;
 #pragma unroll
       for (int j = 0; j < NFC; ++j) {
@@ -794,7 +803,7 @@ __device__ __forceinline__ void h2o_absorb(cmodel M, const LevelState& L, const 
         done = true;
         // the chunk lies on one side of the line: the closest frequency is one of its ends
         const double dmin = ::fmin(fabs(sfq[0] - q.c1), fabs(sfq[2 * 15] - q.c1));
-        if (__any(dmin < sdlim)) {
+        if (wave_any(dmin < sdlim)) {
           double dn[SD_NODES];
 #pragma unroll
           for (int n = 0; n < SD_NODES; ++n) {
@@ -824,7 +833,7 @@ __device__ __forceinline__ void h2o_absorb(cmodel M, const LevelState& L, const 
       for (int j = 0; j < NFC; ++j) {
         const double d1 = sfq[2 * j] - q.c1;
         const bool inner = fabs(d1) < sdlim;
-        if (__any(inner)) {
+        if (wave_any(inner)) {
           const double r1 = inner ? sd_shape(d1) - q.base : 0.0;
           sum[j] = __builtin_fma(q.s, r1, sum[j]);
         }
@@ -920,7 +929,7 @@ __device__ __forceinline__ void dry_absorb(cmodel M, const LevelState& L, const 
   auto far_setup = [&](int k, FarLine& fl) {
     const O2Line q = line_setup(k);
     double P = q.P, Q = q.Q;
-    if (!NODES && second && !__all(fabs(q.dnu) < FAR_SHIFT_GHZ)) { near |= 1ull << k; P = 0.0; Q = 0.0; }
+    if (!NODES && second && !wave_all(fabs(q.dnu) < FAR_SHIFT_GHZ)) { near |= 1ull << k; P = 0.0; Q = 0.0; }
     fl.P = P; fl.Q = Q;
     fl.A2 = 2.0 * __builtin_fma(-q.c1, q.c1, q.df2);
     fl.Bc = q.cc * q.cc;
@@ -1081,20 +1090,23 @@ __device__ __forceinline__ double layer_value(double x1, double x0, bool& neg, b
   const bool same = fabs(d) < 1e-09;
   // x0 < 0 | x1 < 0 | x0 == 0 | x1 == 0 in one comparison (NaN inputs never reach this point)
   const bool nonpos = !(fmin(x1, x0) > 0.0);
-  const bool special = live && (nonpos || same);
   double r;
   const double s = fdiv1(d, sm);
-  if (__all(!live || special || fabs(s) <= LOGMEAN_SMALL_S)) {
+  // the votes as algebra on comparison masks (each ballot is its v_cmp; combining bools first costs two VALU per vote)
+  const wmask m_live = __builtin_amdgcn_ballot_w64(live);
+  const wmask m_special = (__builtin_amdgcn_ballot_w64(nonpos) | __builtin_amdgcn_ballot_w64(same)) & m_live;
+  const wmask m_plain = m_live & ~m_special;                     // lanes whose log-mean is the generic one
+  if ((m_plain & ~__builtin_amdgcn_ballot_w64(fabs(s) <= LOGMEAN_SMALL_S)) == 0ull) {
     KEEP_BRANCH();
     r = (0.5 * sm) * s_over_atanh(s * s);
-  } else if (__all(!live || special || fabs(s) <= LOGMEAN_MID_S)) {
+  } else if ((m_plain & ~__builtin_amdgcn_ballot_w64(fabs(s) <= LOGMEAN_MID_S)) == 0ull) {
     KEEP_BRANCH();
     r = (0.5 * sm) * s_over_atanh_mid(s * s);
   } else {
     KEEP_BRANCH();
     r = log_mean_any(x1, x0, d);
   }
-  if (__any(special)) {                                        // rare below the stratosphere: wave-uniform skip (and 12 VGPRs fewer live)
+  if (m_special != 0ull) {                                     // rare below the stratosphere: wave-uniform skip (and 12 VGPRs fewer live)
     const bool negative = (x0 < 0.0) | (x1 < 0.0);
     const bool zero = x0 == 0.0 || x1 == 0.0;
     if (negative && live) neg = true;
@@ -1110,23 +1122,25 @@ __device__ __forceinline__ double layer_value(double x1, double x0, bool& neg, b
 template <bool ZEROFLG = true>
 __device__ __forceinline__ void layer_value4(double (&x1)[4], const double (&x0)[4], bool& neg, bool live) {
   double s[4];
-  bool small = true, mid = true, special = false;
+  // votes as algebra on comparison masks (see layer_value)
+  const wmask m_live = wballot(live);
+  wmask m_special = 0ull, m_notsmall = 0ull, m_notmid = 0ull;
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
     const double d = x1[k] - x0[k];
-    const bool sp = !(fmin(x1[k], x0[k]) > 0.0) || fabs(d) < 1e-09;
     s[k] = fdiv1(d, x1[k] + x0[k]);
-    special = special || sp;
-    small = small && (sp || fabs(s[k]) <= LOGMEAN_SMALL_S);
-    mid = mid && (sp || fabs(s[k]) <= LOGMEAN_MID_S);
+    const wmask sp = wballot(!(fmin(x1[k], x0[k]) > 0.0)) | wballot(fabs(d) < 1e-09);
+    m_special |= sp;
+    m_notsmall |= ~(sp | wballot(fabs(s[k]) <= LOGMEAN_SMALL_S));
+    m_notmid |= ~(sp | wballot(fabs(s[k]) <= LOGMEAN_MID_S));
   }
-  special = special && live;
+  m_special &= m_live;
   double r[4];
-  if (__all(!live || small)) {
+  if ((m_live & m_notsmall) == 0ull) {
     KEEP_BRANCH();
 #pragma unroll
     for (int k = 0; k < 4; ++k) r[k] = (0.5 * (x1[k] + x0[k])) * s_over_atanh(s[k] * s[k]);
-  } else if (__all(!live || mid)) {
+  } else if ((m_live & m_notmid) == 0ull) {
     KEEP_BRANCH();
 #pragma unroll
     for (int k = 0; k < 4; ++k) r[k] = (0.5 * (x1[k] + x0[k])) * s_over_atanh_mid(s[k] * s[k]);
@@ -1135,7 +1149,7 @@ __device__ __forceinline__ void layer_value4(double (&x1)[4], const double (&x0)
 #pragma unroll
     for (int k = 0; k < 4; ++k) r[k] = log_mean_any(x1[k], x0[k], x1[k] - x0[k]);
   }
-  if (__any(special)) {
+  if (m_special != 0ull) {
     KEEP_BRANCH();
 #pragma unroll 1
     for (int k = 0; k < 4; ++k) {
@@ -1772,14 +1786,14 @@ k_tb_fused(const FusedArgs A) {
         // voted per step
         for (int i = lo; i < hi; ++i) {
           const double tl = tj[i] * ((OPT && fr) ? fr[i] : am);
-          const double E = __all(fabs(tl) <= EXP_SMALL_X) ? fexp_small(-tl) : fexp(-tl);
+          const double E = wave_all(fabs(tl) <= EXP_SMALL_X) ? fexp_small(-tl) : fexp(-tl);
           const double bi = bj[i];
           const double lay = fdiv1(__builtin_fma(bi, E, bprev), 1.0 + E);
           B = __builtin_fma(lay * T, 1.0 - E, B);
           T *= E;
           bprev = bi;
         }
-      } else if (__all(it0 < nthin_all)) {
+      } else if (wave_all(it0 < nthin_all)) {
         // boflay (1 - E) = (B_{i-1} + B_i E) (1 - E)/(1 + E) = (B_{i-1} + B_i E) tanh(tau/2)
         auto step = [&](double tz, double bi) {
           const double tl = tz * am;
@@ -2336,7 +2350,7 @@ k_rte_tau(const RteTauArgs A) {
           B[a] = __builtin_fma(__builtin_fma(bi, E, bprev) * T[a], th, B[a]);
           T[a] *= E;
         };
-        if (__all(!(fabs(tz) * am_max > EXP_TINY_X))) {           // tiny at the longest path: the short series for every elevation
+        if (wave_all(!(fabs(tz) * am_max > EXP_TINY_X))) {           // tiny at the longest path: the short series for every elevation
           KEEP_BRANCH();
 #pragma unroll
           for (int a = 0; a < NA; ++a) {
@@ -2345,7 +2359,7 @@ k_rte_tau(const RteTauArgs A) {
             B[a] = __builtin_fma(__builtin_fma(bi, E, bprev) * T[a], ftanh_half_tiny(tl), B[a]);
             T[a] *= E;
           }
-        } else if (__all(!(fabs(tz) * am_max > EXP_SMALL_X))) {   // thin at the longest path: thin at all of them, one vote
+        } else if (wave_all(!(fabs(tz) * am_max > EXP_SMALL_X))) {   // thin at the longest path: thin at all of them, one vote
           KEEP_BRANCH();
 #pragma unroll
           for (int a = 0; a < NA; ++a) thin_step(a, tz * am[a]);
@@ -2353,7 +2367,7 @@ k_rte_tau(const RteTauArgs A) {
 #pragma unroll
           for (int a = 0; a < NA; ++a) {
             const double tl = tz * am[a];
-            if (__all(!(fabs(tl) > EXP_SMALL_X))) {
+            if (wave_all(!(fabs(tl) > EXP_SMALL_X))) {
               thin_step(a, tl);
             } else {
               const double E = fexp(-tl);
