@@ -81,8 +81,10 @@ __device__ __forceinline__ double fdiv(double x, double d) {
 #endif
 }
 
-// exp(x) for the kernels' bounded arguments: Cody-Waite reduction + degree-13 Taylor on |r| <= ln2/2
-// (truncation 4e-18), scaled by v_ldexp_f64 (which also gives the right 0 / inf at the range ends).
+// exp(x) for the kernels' bounded arguments: Cody-Waite reduction + a degree-11 polynomial on |r| <= ln2/2
+// (1 + r + r^2 g(r), g fitted at the Chebyshev nodes of the interval: 1.7e-17 relative; the degree-13 Taylor
+// series it replaces had 4e-18 and two more steps), scaled by v_ldexp_f64 (which also gives the right 0 / inf at
+// the range ends).
 // ocml's exp spends two VALU instructions per Horner step (v_mov of the 64-bit constant + v_fmac);
 // here each constant rides in an SGPR pair (materialised by s_mov, off the VALU port), so a step
 // is ONE v_fma_f64.  ~19 VALU instead of ~35; max relative error measured < 4e-16.
@@ -94,27 +96,38 @@ __device__ __forceinline__ double fexp(double x) {
   const double k = __builtin_rint(x * 1.4426950408889634074);
   double r = __builtin_fma(k, -6.93147180369123816490e-01, x);
   r = __builtin_fma(k, -1.90821492927058770002e-10, r);
-  double p = 1.6059043836821613e-10;                 // 1/13!
-  MWRT_FMA_SC(p, r, 2.0876756987868100e-09);         // 1/12!
-  MWRT_FMA_SC(p, r, 2.5052108385441720e-08);         // 1/11!
-  MWRT_FMA_SC(p, r, 2.7557319223985893e-07);         // 1/10!
-  MWRT_FMA_SC(p, r, 2.7557319223985888e-06);         // 1/9!
-  MWRT_FMA_SC(p, r, 2.4801587301587302e-05);         // 1/8!
-  MWRT_FMA_SC(p, r, 1.9841269841269841e-04);         // 1/7!
-  MWRT_FMA_SC(p, r, 1.3888888888888889e-03);         // 1/6!
-  MWRT_FMA_SC(p, r, 8.3333333333333332e-03);         // 1/5!
-  MWRT_FMA_SC(p, r, 4.1666666666666664e-02);         // 1/4!
-  MWRT_FMA_SC(p, r, 1.6666666666666666e-01);         // 1/3!
-  p = __builtin_fma(p, r, 0.5);
+  double p = 2.5100569275813683e-08;
+  MWRT_FMA_SC(p, r, 2.762032742826824e-07);
+  MWRT_FMA_SC(p, r, 2.75572680728901e-06);
+  MWRT_FMA_SC(p, r, 2.4801520792572694e-05);
+  MWRT_FMA_SC(p, r, 0.00019841269863303223);
+  MWRT_FMA_SC(p, r, 0.0013888888917538296);
+  MWRT_FMA_SC(p, r, 0.008333333333330011);
+  MWRT_FMA_SC(p, r, 0.04166666666662348);
+  MWRT_FMA_SC(p, r, 0.16666666666666669);
+  MWRT_FMA_SC(p, r, 0.5000000000000001);
   p = __builtin_fma(p, r, 1.0);
   p = __builtin_fma(p, r, 1.0);
   return __builtin_amdgcn_ldexp(p, (int)k);
 #endif
 }
 
+// (2 atanh(s)/s - 2)/z = 2/3 + 2z/5 + ..., z = s^2 <= 0.1716^2, as a degree-6 polynomial fitted at the Chebyshev nodes of
+// the interval: 2 atanh(s)/s to 4.6e-18 relative in 7 steps (the Taylor series needs 10 for 5e-17)
+__device__ __forceinline__ double two_atanh_tail(double z) {
+  double p = 0.14616878919029822;
+  MWRT_FMA_SC(p, z, 0.15331686868638428);
+  MWRT_FMA_SC(p, z, 0.1818289017031397);
+  MWRT_FMA_SC(p, z, 0.22222211120449298);
+  MWRT_FMA_SC(p, z, 0.2857142862606338);
+  MWRT_FMA_SC(p, z, 0.3999999999989931);
+  MWRT_FMA_SC(p, z, 0.666666666666667);
+  return p;
+}
+
 // log(x), x > 0 finite and normal (layer ratios of positive absorption coefficients): frexp to
-// m in [sqrt(1/2), sqrt(2)), s = (m-1)/(m+1), log m = 2 s (1 + z/3 + z^2/5 + ... + z^10/21), z = s^2
-// (|s| <= 0.1716: truncation 5e-17).  Keeps full RELATIVE accuracy as x -> 1, which is what the
+// m in [sqrt(1/2), sqrt(2)), s = (m-1)/(m+1), log m = 2 s (1 + z/3 + z^2/5 + ...) = s (2 + z two_atanh_tail(z)), z = s^2
+// (|s| <= 0.1716).  Keeps full RELATIVE accuracy as x -> 1, which is what the
 // log-mean of two nearly equal levels needs.  ~33 VALU against ~50 for ocml's log.
 __device__ __forceinline__ double flog(double x) {
 #if MWRT_EXACT_DIV
@@ -131,49 +144,39 @@ __device__ __forceinline__ double flog(double x) {
   r = __builtin_fma(r, __builtin_fma(-den, r, 1.0), r);
   const double s = num * r;
   const double z = s * s;
-  double p = 9.5238095238095233e-02;                    // 2/21
-  MWRT_FMA_SC(p, z, 1.0526315789473684e-01);            // 2/19
-  MWRT_FMA_SC(p, z, 1.1764705882352941e-01);            // 2/17
-  MWRT_FMA_SC(p, z, 1.3333333333333333e-01);            // 2/15
-  MWRT_FMA_SC(p, z, 1.5384615384615385e-01);            // 2/13
-  MWRT_FMA_SC(p, z, 1.8181818181818182e-01);            // 2/11
-  MWRT_FMA_SC(p, z, 2.2222222222222221e-01);            // 2/9
-  MWRT_FMA_SC(p, z, 2.8571428571428570e-01);            // 2/7
-  MWRT_FMA_SC(p, z, 4.0000000000000002e-01);            // 2/5
-  MWRT_FMA_SC(p, z, 6.6666666666666663e-01);            // 2/3
+  const double p = two_atanh_tail(z);                   // (2 atanh(s)/s - 2) / z
   const double ed = (double)e;
   const double lm = __builtin_fma(s * z, p, s + s);     // log(m)
   return __builtin_fma(ed, 6.93147180369123816490e-01, __builtin_fma(ed, 1.90821492927058770002e-10, lm));
 #endif
 }
 
-// exp(x) for |x| <= 1/8 with no range reduction: degree-10 Taylor (truncation 3e-18).  11 VALU.
+// exp(x) for |x| <= 1/8 with no range reduction: 1 + x + x^2 g(x), g of degree 7 fitted at the Chebyshev nodes
+// (2.2e-18 relative).  9 VALU.
 // Thin layers (tau * airmass <= 1/8) are the rule for the K-band channels at every level and angle.
 constexpr double EXP_SMALL_X = 0.125;
 __device__ __forceinline__ double fexp_small(double x) {
-  double p = 2.7557319223985891e-07;                 // 1/10!
-  MWRT_FMA_SC(p, x, 2.7557319223985888e-06);         // 1/9!
-  MWRT_FMA_SC(p, x, 2.4801587301587302e-05);         // 1/8!
-  MWRT_FMA_SC(p, x, 1.9841269841269841e-04);         // 1/7!
-  MWRT_FMA_SC(p, x, 1.3888888888888889e-03);         // 1/6!
-  MWRT_FMA_SC(p, x, 8.3333333333333332e-03);         // 1/5!
-  MWRT_FMA_SC(p, x, 4.1666666666666664e-02);         // 1/4!
-  MWRT_FMA_SC(p, x, 1.6666666666666666e-01);         // 1/3!
-  p = __builtin_fma(p, x, 0.5);
+  double p = 2.756514908613403e-06;
+  MWRT_FMA_SC(p, x, 2.4810200365624755e-05);
+  MWRT_FMA_SC(p, x, 0.00019841269076602318);
+  MWRT_FMA_SC(p, x, 0.001388888804772704);
+  MWRT_FMA_SC(p, x, 0.008333333333357229);
+  MWRT_FMA_SC(p, x, 0.04166666666692954);
+  MWRT_FMA_SC(p, x, 0.16666666666666666);
+  MWRT_FMA_SC(p, x, 0.4999999999999999);
   p = __builtin_fma(p, x, 1.0);
   return __builtin_fma(p, x, 1.0);
 }
 
-// tanh(x/2) = (1 - e^-x) / (1 + e^-x) for 0 <= x <= 1/8: odd series through x^11 (next term 1e-17 relative).
-// 7 VALU; in the thin-layer RTE step it replaces 1 - E, 1 + E and their quotient (9 issue slots), and has none
+// tanh(x/2) = (1 - e^-x) / (1 + e^-x) for 0 <= x <= 1/8: x (1/2 + u g(u)), u = x^2, g of degree 3 fitted at the Chebyshev
+// nodes of [0, 1/64] (6e-17 relative).  6 VALU; in the thin-layer RTE step it replaces 1 - E, 1 + E and their quotient (9 issue slots), and has none
 // of the cancellation of 1 - E.
 __device__ __forceinline__ double ftanh_half_small(double x) {
   const double u = x * x;
-  double p = -4.3277517235850570e-06;                // -691/159667200
-  MWRT_FMA_SC(p, u, 4.2713844797178131e-05);         // 31/725760
-  MWRT_FMA_SC(p, u, -4.2162698412698413e-04);        // -17/40320
-  MWRT_FMA_SC(p, u, 4.1666666666666666e-03);         // 1/240
-  MWRT_FMA_SC(p, u, -4.1666666666666664e-02);        // -1/24
+  double p = 4.257889640378761e-05;
+  MWRT_FMA_SC(p, u, -0.0004216256671577941);
+  MWRT_FMA_SC(p, u, 0.004166666662552237);
+  MWRT_FMA_SC(p, u, -0.04166666666666466);
   p = __builtin_fma(p, u, 0.5);
   return p * x;
 }
@@ -1014,21 +1017,18 @@ __device__ __forceinline__ void dry_absorb(cmodel M, const LevelState& L, const 
 // the usual case (wave vote): one division and a 10-term series instead of a division, a full log
 // (frexp, second division, series) and a third division.  It is also better conditioned than the
 // quotient form, which loses up to 1e-7 relative when x1 - x0 is just above the 1e-9 switch.
-constexpr double LOGMEAN_SMALL_S = 0.1715;      // |s| <= this: series truncation < 1.1e-19
+constexpr double LOGMEAN_SMALL_S = 0.1715;      // |s| <= this: inside the interval s_over_atanh was fitted on
 
-// s / atanh(s) = 1 - z/3 - 4 z^2/45 - 44 z^3/945 - ... (z = s^2; coefficients by series inversion, truncation after
-// z^10 < 1.1e-19 at |s| = 0.1715): the log-mean is (x1 + x0)/2 times this
+// s / atanh(s) = 1 - z/3 - 4 z^2/45 - 44 z^3/945 - ... (z = s^2) = 1 + z g(z), g of degree 6 fitted at the Chebyshev nodes
+// of [0, 0.1716^2] (1.1e-18 relative; the Taylor series needs ten terms): the log-mean is (x1 + x0)/2 times this
 __device__ __forceinline__ double s_over_atanh(double z) {
-  double q = -8.2312065673505011548e-03;
-  MWRT_FMA_SC(q, z, -9.5160731945278989134e-03);
-  MWRT_FMA_SC(q, z, -1.1203745637718733130e-02);
-  MWRT_FMA_SC(q, z, -1.3502765051265933100e-02);
-  MWRT_FMA_SC(q, z, -1.6787551856334925118e-02);
-  MWRT_FMA_SC(q, z, -2.1796804019026241248e-02);
-  MWRT_FMA_SC(q, z, -3.0194003527336860670e-02);
-  MWRT_FMA_SC(q, z, -4.6560846560846560847e-02);
-  MWRT_FMA_SC(q, z, -8.8888888888888888889e-02);
-  MWRT_FMA_SC(q, z, -3.3333333333333333333e-01);
+  double q = -0.014721548786632996;
+  MWRT_FMA_SC(q, z, -0.01673734010479199);
+  MWRT_FMA_SC(q, z, -0.02179782053718046);
+  MWRT_FMA_SC(q, z, -0.03019399300258251);
+  MWRT_FMA_SC(q, z, -0.04656084661263456);
+  MWRT_FMA_SC(q, z, -0.08888888888879345);
+  MWRT_FMA_SC(q, z, -0.33333333333333337);
   return __builtin_fma(q, z, 1.0);
 }
 
@@ -1066,17 +1066,7 @@ __device__ __forceinline__ double log_mean_any(double x1, double x0, double d) {
   e = hi ? e + 1 : (lo ? e - 1 : e);
   const double sp = fdiv1(x1 - x0s, x1 + x0s);                     // |s'| <= 0.1716
   const double z = sp * sp;
-  double p = 9.5238095238095233e-02;                               // 2/21: 2 atanh(s)/s = 2 + 2z/3 + 2z^2/5 + ...
-  MWRT_FMA_SC(p, z, 1.0526315789473684e-01);
-  MWRT_FMA_SC(p, z, 1.1764705882352941e-01);
-  MWRT_FMA_SC(p, z, 1.3333333333333333e-01);
-  MWRT_FMA_SC(p, z, 1.5384615384615385e-01);
-  MWRT_FMA_SC(p, z, 1.8181818181818182e-01);
-  MWRT_FMA_SC(p, z, 2.2222222222222221e-01);
-  MWRT_FMA_SC(p, z, 2.8571428571428570e-01);
-  MWRT_FMA_SC(p, z, 4.0000000000000002e-01);
-  MWRT_FMA_SC(p, z, 6.6666666666666663e-01);
-  p = __builtin_fma(p, z, 2.0);
+  const double p = __builtin_fma(two_atanh_tail(z), z, 2.0);      // 2 atanh(s)/s = 2 + 2z/3 + 2z^2/5 + ...
   const double ed = (double)e;
   const double ln = __builtin_fma(ed, 6.93147180369123816490e-01, __builtin_fma(ed, 1.90821492927058770002e-10, sp * p));
   return fdiv1(d, ln);
