@@ -245,6 +245,18 @@ int launch_fused(mwrt_context* c, int nfc, FusedArgs a, int64_t nprof, hipStream
   // frequency chunks per profile the flags are preset here and the kernel only lowers/raises them
   a.write_valid = nchunks == 1;
   if (!a.write_valid) HIP_TRY(hipMemsetAsync(a.valid, 1, (size_t)nprof, st));
+#if MWRT_PHASE_CLOCK
+  // diagnostic build: stamps of the LAST launch go to $MWRT_PHASE_DUMP as raw int64 [nprof][4][10] (100-MHz wall clock; slots 8, 9 = HW_ID, XCC_ID)
+  static long long* d_phase = nullptr; static size_t phase_cap = 0;
+  const char* dump = std::getenv("MWRT_PHASE_DUMP");
+  const size_t phase_n = (size_t)nprof * 4 * 10;
+  a.phase = nullptr;
+  if (dump && nchunks == 1) {
+    if (phase_cap < phase_n) { if (d_phase) (void)hipFree(d_phase); HIP_TRY(hipMalloc((void**)&d_phase, phase_n * 8)); phase_cap = phase_n; }
+    HIP_TRY(hipMemsetAsync(d_phase, 0, phase_n * 8, st));
+    a.phase = d_phase;
+  }
+#endif
   timing_begin(c, st);
   hipError_t e;
   switch (nfc) {                                    // one translation unit per chunk width (csrc/mwrt_inst.hip)
@@ -254,6 +266,14 @@ int launch_fused(mwrt_context* c, int nfc, FusedArgs a, int64_t nprof, hipStream
   }
   timing_end(c, st);
   HIP_TRY(e);
+#if MWRT_PHASE_CLOCK
+  if (a.phase) {
+    std::vector<long long> h(phase_n);
+    HIP_TRY(hipStreamSynchronize(st));
+    HIP_TRY(hipMemcpy(h.data(), d_phase, phase_n * 8, hipMemcpyDeviceToHost));
+    if (FILE* f = std::fopen(dump, "wb")) { std::fwrite(h.data(), 8, phase_n, f); std::fclose(f); }
+  }
+#endif
   return MWRT_OK;
 }
 

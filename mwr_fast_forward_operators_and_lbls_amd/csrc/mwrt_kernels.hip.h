@@ -66,6 +66,31 @@ __device__ __forceinline__ int div_small(int n, int d, unsigned magic) {
 #ifndef MWRT_ABLATE
 #define MWRT_ABLATE 0
 #endif
+// diagnostic build (tools/phase_timeline.sh): lane 0 of every wave of k_tb_fused stamps the 100-MHz wall clock at its phase
+// boundaries into FusedArgs::phase [workgroup][wave][10] (slots 8, 9: HW_ID and XCC_ID of the wave).  Always 0 in the shipped library.
+#ifndef MWRT_PHASE_CLOCK
+#define MWRT_PHASE_CLOCK 0
+#endif
+// Issue priority by phase.  A SIMD issues from its OLDEST ready wave first, so of the three or four workgroups a CU holds the
+// first one dispatched runs almost as if alone and the last one gets the gaps: in the single resident round of the headline
+// shape (1000 workgroups, four per CU, all started within 0.3 us) the phase stamps of a -DMWRT_PHASE_CLOCK=1 build show the
+// four workgroups of every CU leaving at 70 / 81 / 108 / 111 us -- the last ones run their final 30 us with one or two waves
+// per SIMD, latency-bound.  s_setprio beats age: a wave in an EARLIER phase gets the higher priority (3 water lines,
+// 2 oxygen lines, 1 layer step + first RTE pass, 0 second RTE pass), so the laggards of a SIMD catch up at every phase
+// change and all waves finish together (88 ... 101 us): 116 -> 105 us.  -DMWRT_NO_SETPRIO=1 builds without it (A/B timing).
+#ifndef MWRT_NO_SETPRIO
+#define MWRT_NO_SETPRIO 0
+#endif
+#if MWRT_NO_SETPRIO
+#define MWRT_SETPRIO(n) do { } while (0)
+#else
+#define MWRT_SETPRIO(n) __builtin_amdgcn_s_setprio(n)
+#endif
+#if MWRT_PHASE_CLOCK
+#define MWRT_STAMP(k) do { if (A.phase && lane == 0) A.phase[((int64_t)blockIdx.x * 4 + wave) * 10 + (k)] = (long long)wall_clock64(); } while (0)
+#else
+#define MWRT_STAMP(k) do { } while (0)
+#endif
 
 // x / d with v_rcp_f64 + two Newton steps (~1.5 ulp; parity bar is 1e-6 K, budget 0.01 K).
 __device__ __forceinline__ double fdiv(double x, double d) {
@@ -1404,6 +1429,9 @@ struct FusedArgs {
   const double* awet_in; const double* adry_in;
   const LineMasks* masks[MAX_MULTI];   // per model: LineMasks of every frequency chunk (host-computed)
   const double* o3n;       // OPT: ozone number density [nprof][nlev] molecules m-3, or null
+#if MWRT_PHASE_CLOCK
+  long long* phase;        // diagnostic build only: [nprof][4][10] wall-clock stamps + HW_ID, XCC_ID
+#endif
 };
 
 // NaN / negative-absorption exit: every output of this (profile, chunk) becomes NaN
@@ -1472,6 +1500,13 @@ k_tb_fused(const FusedArgs A) {
   __shared__ int s_flag;
   __shared__ double sfq[5 * NFC + 2];                     // {f, f^2} per slot, {fmin, fmax}, N2 fdep, 1/f, cosmic-background Planck term per slot
 
+  MWRT_STAMP(0);
+#if MWRT_PHASE_CLOCK
+  if (A.phase && lane == 0) {
+    A.phase[((int64_t)blockIdx.x * 4 + wave) * 10 + 8] = (long long)__builtin_amdgcn_s_getreg((31 << 11) | 4);     // HW_REG_HW_ID
+    A.phase[((int64_t)blockIdx.x * 4 + wave) * 10 + 9] = (long long)__builtin_amdgcn_s_getreg((31 << 11) | 20);    // HW_REG_XCC_ID
+  }
+#endif
   // uniform frequency chunk; slots beyond nfc reuse the last valid one (results discarded)
   if (tid == 0) s_flag = 0;
   if (tid < NFC) {
@@ -1535,8 +1570,14 @@ k_tb_fused(const FusedArgs A) {
     const double e = goff_gratch_e(ti, rhi);
     const LevelState L = level_state(pi, ti, e);
     const LineMasks lm = load_masks(A.masks[mi], blockIdx.y);
+    MWRT_STAMP(1);
+    MWRT_SETPRIO(3);
     h2o_absorb<NFC>(M, L, sfq, lm, awet);
+    MWRT_STAMP(2);
+    MWRT_SETPRIO(2);
     dry_absorb<NFC>(M, L, sfq, lm, adry);
+    MWRT_SETPRIO(1);
+    MWRT_STAMP(3);
     if constexpr (OPT) {
       if (A.o3n) x_absorb<NFC>(M, ti, pi, o3n, sfq, adry);       // clearsky_absorption(..., o3n): ozone joins the dry term
     }
@@ -1614,6 +1655,7 @@ k_tb_fused(const FusedArgs A) {
       __syncthreads();                          // the rows are about to be refilled with tau / B
     }
   }
+  MWRT_STAMP(4);
   if (neg) atomicOr(&s_flag, 2);
   __syncthreads();
   if (s_flag) {                               // pyrtlib raises ValueError here: flag 2, NaN out
@@ -1644,6 +1686,7 @@ k_tb_fused(const FusedArgs A) {
   for (int h = 0; h < NPASS; ++h) {
     const int nfk = min(NFK, nfc - h * NFK);            // frequencies live in this pass (uniform)
     if (nfk <= 0) break;
+    if (h > 0) MWRT_SETPRIO(0);
     if (h > 0) __syncthreads();                          // previous pass has finished reading LDS
     const int nseg = A.g.nseg[h], seglen = A.g.seglen[h];
     const int npairs = nfk * nang;
@@ -1824,6 +1867,7 @@ k_tb_fused(const FusedArgs A) {
       }
       part[2 * it + 0] = B; part[2 * it + 1] = T;
     }
+    MWRT_STAMP(5 + h);
     __syncthreads();
     for (int pr = tid; pr < npairs; pr += nthreads) {
       const int jj = div_small(pr, nang, A.g.magic_nang);
@@ -1870,6 +1914,7 @@ k_tb_fused(const FusedArgs A) {
     if (A.duct && A.duct[pin]) { if (tid == 0) A.valid[prof] = 3; return; }
   }
   if (A.write_valid && tid == 0) A.valid[prof] = 1;
+  MWRT_STAMP(7);
 }
 
 // ---------------------------------------------------------------------------------------------
