@@ -362,6 +362,7 @@ void chunk_masks(const mwrt_model_desc& t, const double* frq, int nf, int nfc, s
     for (int j = j0; j < j1; ++j) { ulo = std::min(ulo, frq[j] * frq[j]); uhi = std::max(uhi, frq[j] * frq[j]); }
     lm.vf_u0 = 0.5 * (ulo + uhi);
     lm.vf_h = std::max(0.5 * (uhi - ulo), 1.0);
+    lm.vf_invh = 1.0 / lm.vf_h;
     auto very_far = [&](double c) {
       const double cl = std::max(c - 2.0, 0.0), ch = c + 2.0;
       const double plo = cl * cl - 100.0, phi = ch * ch;             // real part of the poles lies in [plo, phi]

@@ -307,7 +307,7 @@ struct LineMasks {
   unsigned h2o_sdint;          // speed-dependent lines far enough from the chunk (>= 3 GHz and 5 spans) for the half-sampled shape
   unsigned h2o_vfar;           // "very far" lines: summed as ONE Taylor polynomial in f^2 about the chunk's middle (vfar_add)
   unsigned long long o2_vfar;
-  double vf_u0, vf_h;          // middle and half range of the chunk's f^2 values [GHz^2] (vf_h >= 1)
+  double vf_u0, vf_h, vf_invh; // middle and half range of the chunk's f^2 values [GHz^2] (vf_h >= 1), 1 / vf_h
 };
 
 // The sets depend on the chunk's frequencies and the table only: the host computes them once per (model, frequency
@@ -319,7 +319,7 @@ __device__ __forceinline__ LineMasks load_masks(const LineMasks* table, int chun
   LineMasks lm;
   lm.o2_far = q->o2_far; lm.h2o_far = q->h2o_far; lm.h2o_none = q->h2o_none; lm.h2o_res = q->h2o_res; lm.h2o_sd = q->h2o_sd;
   lm.h2o_sdfar = q->h2o_sdfar; lm.h2o_sdint = q->h2o_sdint;
-  lm.h2o_vfar = q->h2o_vfar; lm.o2_vfar = q->o2_vfar; lm.vf_u0 = q->vf_u0; lm.vf_h = q->vf_h;
+  lm.h2o_vfar = q->h2o_vfar; lm.o2_vfar = q->o2_vfar; lm.vf_u0 = q->vf_u0; lm.vf_h = q->vf_h; lm.vf_invh = q->vf_invh;
   return lm;
 }
 
@@ -495,29 +495,57 @@ struct FarLine { double P, Q, A2, Bc; };
 // v_rcp_f64 costs about three FMA issue slots and delivers 2^-23, so a reciprocal + Newton step is 5 of
 // the 9 slots a line-frequency term costs on its own; shared by four lines the term costs 6.6.
 // 24 FMA-class instructions + 1 rcp per frequency (products stay < 1e48 for centres <= 1 THz).
+// A wave issues in order, and a SIMD holds only three of these waves: the reciprocal and the Newton step that end a
+// frequency are a serial tail, and the compiler (scheduling for register pressure) runs one frequency after the other.
+// Here two frequencies go side by side and the loop is software-pipelined by hand: the reciprocals of one pair are issued,
+// then the 52 independent instructions of the NEXT pair's numerators and denominators, then the first pair's Newton step and
+// accumulation; the f^2 values are read from LDS two pairs ahead.  Scheduling barriers keep the compiler from undoing it.
+#define MWRT_STAGE() __builtin_amdgcn_sched_barrier(0)
 template <int NFC>
 __device__ __forceinline__ void far_quad_accumulate(const double* sfq, const FarLine& a, const FarLine& b,
                                                     const FarLine& c, const FarLine& d, double (&sum)[NFC]) {
+  static_assert(NFC % 2 == 0, "frequencies are taken in pairs");
+  auto front = [&](const double (&f2s)[2], double (&den)[2], double (&num)[2]) {
 #pragma unroll
-  for (int j = 0; j < NFC; ++j) {
-    const double f2 = sfq[2 * j + 1];
-    const double d0 = __builtin_fma(f2, f2 + a.A2, a.Bc);
-    const double d1 = __builtin_fma(f2, f2 + b.A2, b.Bc);
-    const double d2 = __builtin_fma(f2, f2 + c.A2, c.Bc);
-    const double d3 = __builtin_fma(f2, f2 + d.A2, d.Bc);
-    const double n0 = __builtin_fma(f2, a.P, a.Q);
-    const double n1 = __builtin_fma(f2, b.P, b.Q);
-    const double n2 = __builtin_fma(f2, c.P, c.Q);
-    const double n3 = __builtin_fma(f2, d.P, d.Q);
-    const double p01 = d0 * d1, p23 = d2 * d3;
-    const double m01 = __builtin_fma(n0, d1, n1 * d0);
-    const double m23 = __builtin_fma(n2, d3, n3 * d2);
-    const double den = p01 * p23;
-    const double num = __builtin_fma(m01, p23, m23 * p01);
-    double r = __builtin_amdgcn_rcp(den);
-    r = __builtin_fma(r, __builtin_fma(-den, r, 1.0), r);
-    sum[j] = __builtin_fma(num, r, sum[j]);
+    for (int g = 0; g < 2; ++g) {
+      const double f2 = f2s[g];
+      const double d0 = __builtin_fma(f2, f2 + a.A2, a.Bc);
+      const double d1 = __builtin_fma(f2, f2 + b.A2, b.Bc);
+      const double d2 = __builtin_fma(f2, f2 + c.A2, c.Bc);
+      const double d3 = __builtin_fma(f2, f2 + d.A2, d.Bc);
+      const double n0 = __builtin_fma(f2, a.P, a.Q);
+      const double n1 = __builtin_fma(f2, b.P, b.Q);
+      const double n2 = __builtin_fma(f2, c.P, c.Q);
+      const double n3 = __builtin_fma(f2, d.P, d.Q);
+      const double p01 = d0 * d1, p23 = d2 * d3;
+      const double m01 = __builtin_fma(n0, d1, n1 * d0);
+      const double m23 = __builtin_fma(n2, d3, n3 * d2);
+      den[g] = p01 * p23;
+      num[g] = __builtin_fma(m01, p23, m23 * p01);
+    }
+  };
+  double den[2], num[2], r[2];
+  double f2c[2] = {sfq[1], sfq[3]};
+  double f2n[2] = {sfq[(NFC > 2) ? 5 : 1], sfq[(NFC > 2) ? 7 : 3]};
+  front(f2c, den, num);
+  r[0] = __builtin_amdgcn_rcp(den[0]); r[1] = __builtin_amdgcn_rcp(den[1]);
+#pragma unroll
+  for (int j = 0; j < NFC; j += 2) {
+    double den_n[2] = {1.0, 1.0}, num_n[2] = {0.0, 0.0}, f2p[2] = {0.0, 0.0};
+    if (j + 4 < NFC) { f2p[0] = sfq[2 * (j + 4) + 1]; f2p[1] = sfq[2 * (j + 5) + 1]; }      // in flight for two trips
+    MWRT_STAGE();
+    if (j + 2 < NFC) front(f2n, den_n, num_n);
+    MWRT_STAGE();
+    const double e0 = __builtin_fma(-den[0], r[0], 1.0), e1 = __builtin_fma(-den[1], r[1], 1.0);
+    r[0] = __builtin_fma(r[0], e0, r[0]); r[1] = __builtin_fma(r[1], e1, r[1]);
+    sum[j] = __builtin_fma(num[0], r[0], sum[j]); sum[j + 1] = __builtin_fma(num[1], r[1], sum[j + 1]);
+    if (j + 2 < NFC) {
+      den[0] = den_n[0]; den[1] = den_n[1]; num[0] = num_n[0]; num[1] = num_n[1];
+      r[0] = __builtin_amdgcn_rcp(den[0]); r[1] = __builtin_amdgcn_rcp(den[1]);
+      f2n[0] = f2p[0]; f2n[1] = f2p[1];
+    }
   }
+  MWRT_STAGE();
 }
 
 // VERY far lines: a line whose poles in u = f^2 (u ~ c^2 -+ 2 i c w) lie at >= 1/VF_RATIO_MAX half ranges from the middle u0
@@ -549,15 +577,23 @@ __device__ __forceinline__ void vfar_add(const FarLine& fl, double u0, double h,
   }
 }
 template <int NFC>
-__device__ __forceinline__ void vfar_eval(const double* sfq, double u0, double h, const double (&acc)[VF_TERMS], double (&sum)[NFC]) {
-  const double invh = 1.0 / h, mu = -u0 * invh;               // wave-uniform
+__device__ __forceinline__ void vfar_eval(const double* sfq, double invh, double mu /* = -u0 / h */, const double (&acc)[VF_TERMS], double (&sum)[NFC]) {
+  // the Horner chains of several frequencies side by side (each is VF_TERMS - 1 dependent FMAs)
+  constexpr int G = (NFC % 7 == 0) ? 7 : ((NFC % 4 == 0) ? 4 : 2);
+  static_assert(NFC % G == 0, "group width");
 #pragma unroll
-  for (int j = 0; j < NFC; ++j) {
-    const double x = __builtin_fma(sfq[2 * j + 1], invh, mu);
-    double p = acc[VF_TERMS - 1];
+  for (int j0 = 0; j0 < NFC; j0 += G) {
+    double x[G], p[G];
 #pragma unroll
-    for (int k = VF_TERMS - 2; k >= 0; --k) p = __builtin_fma(p, x, acc[k]);
-    sum[j] += p;
+    for (int g = 0; g < G; ++g) { x[g] = __builtin_fma(sfq[2 * (j0 + g) + 1], invh, mu); p[g] = acc[VF_TERMS - 1]; }
+#pragma unroll
+    for (int k = VF_TERMS - 2; k >= 0; --k) {
+#pragma unroll
+      for (int g = 0; g < G; ++g) p[g] = __builtin_fma(p[g], x[g], acc[k]);
+      MWRT_STAGE();
+    }
+#pragma unroll
+    for (int g = 0; g < G; ++g) sum[j0 + g] += p[g];
   }
 }
 
@@ -675,7 +711,7 @@ __device__ __forceinline__ void h2o_absorb(cmodel M, const LevelState& L, const 
       vfar_add(q, lm.vf_u0, lm.vf_h, acc);
     }
     LDS_RELOAD_FENCE();
-    vfar_eval<NFC>(sfq, lm.vf_u0, lm.vf_h, acc, sum);
+    vfar_eval<NFC>(sfq, lm.vf_invh, -lm.vf_u0 * lm.vf_invh, acc, sum);
   }
   for (unsigned m = setQ & ~leftA; m;) {
     FarLine q0, q1, q2, q3;
@@ -972,7 +1008,7 @@ __device__ __forceinline__ void dry_absorb(cmodel M, const LevelState& L, const 
       vfar_add(q, lm.vf_u0, lm.vf_h, acc);
     }
     LDS_RELOAD_FENCE();
-    vfar_eval<NFC>(sfq, lm.vf_u0, lm.vf_h, acc, sum);
+    vfar_eval<NFC>(sfq, lm.vf_invh, -lm.vf_u0 * lm.vf_invh, acc, sum);
   }
   for (unsigned long long m = setQ & ~leftA; m;) {
     FarLine q0, q1, q2, q3;
