@@ -1087,6 +1087,32 @@ def test_windowed_absorption_matches_oracle_and_the_direct_kernel(gpu_ctx, name)
             gpu_ctx.set_absorption_mode(0)
 
 
+@pytest.mark.parametrize("band", ["hatpro", "g-band", "w-band", "340"])
+@pytest.mark.parametrize("name", ["R98", "R24"])
+def test_very_far_line_sets(gpu_ctx, name, band):
+    """The lines whose poles in f^2 lie >= 62 half-ranges from the middle of a chunk go through ONE Taylor polynomial per
+    species (vfar_add / vfar_eval): chunks where the set is the submillimetre lines (HATPRO), where it starts
+    higher (183-GHz band), where the chunk is narrow (90 GHz) and where the poles lie BELOW the chunk (340 GHz: the 60-GHz
+    band, the 22- and 118-GHz lines).  Absorption against the oracle to 2e-11 relative, TBs to the usual bar."""
+    frq = {"hatpro": pr.HATPRO_FRQS,
+           "g-band": np.array([175.31, 178.31, 180.31, 181.31, 182.31, 184.31, 186.31, 190.31]),
+           "w-band": np.array([89.0, 89.5, 90.0, 90.5, 91.0, 91.5]),
+           "340": np.array([338.0, 339.0, 340.0, 341.0, 342.0, 343.0])}[band]
+    P = pr.synthetic_profiles(4, 77)
+    m = sp.get_model(name)
+    aw_g, ad_g = gpu_ctx.absorption_batch(name, P["p"], P["t"], P["rh"], frq)
+    for i in (0, 3):
+        aw, ad = lo.absorption_profile(m, P["p"][i], P["t"][i], P["rh"][i], frq)
+        assert np.allclose(aw_g[i], aw, rtol=2e-11, atol=1e-300), (band, np.abs(aw_g[i] / aw - 1).max())
+        assert np.allclose(ad_g[i], ad, rtol=2e-11, atol=1e-300), (band, np.abs(ad_g[i] / ad - 1).max())
+    ang = np.array([90.0, 30.0, 5.4])
+    tb, valid = gpu_ctx.tb_batch(name, P["z"], P["p"], P["t"], P["rh"], frq, ang)
+    assert valid.tolist() == [1] * 4
+    for i in (1, 2):
+        ref, _ = oracle_tb(m, P, i, frq, ang)
+        assert np.abs(tb[i] - ref["tbtotal"]).max() <= TOL_K
+
+
 def test_windowed_path_with_fuzzed_tables(gpu_ctx):
     """Perturbed line tables with large second-order shifts and speed dependence on random lines, through the automatic
     fine-grid TB path (windowed K1 -> alpha -> K2), against the oracle."""
