@@ -5,6 +5,7 @@
 #define MWRT_HOST_TU 1      // this translation unit owns the non-template kernels
 #include "mwrt_inst.hip.h"
 
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -507,6 +508,27 @@ void build_windows(const mwrt_model_desc& t, const double* frq, int nf, WindowSe
     }
     if (ok) { spans[i] = m; spans.erase(spans.begin() + (long)i + 1); ++i; }           // (a merged window is not merged again)
     else ++i;
+  }
+  // Workgroups are dispatched in grid order (profiles fastest, then windows): the EXPENSIVE windows go first, so that the
+  // last, partly filled round of the launch is made of cheap ones (the oxygen band sits at the end of a 20-60 GHz grid).
+  // Cost per frequency, roughly, in instructions: a floor, 12 per oxygen line evaluated directly, the speed-dependent shape
+  // where some level can be inside its 10 half-widths.
+  if (std::getenv("MWRT_WIN_GRID_ORDER") == nullptr) {                                   // (diagnostic: keep the grid order)
+    auto cost = [&](const Span& sp) {
+      int b, e; bounds(sp, &b, &e);
+      WinDesc d{};
+      window_far_sets(t, frq[b], frq[e], &d);
+      const unsigned long long all_o2 = t.n_o2 >= 64 ? ~0ull : ((1ull << t.n_o2) - 1ull);
+      double per_f = 150.0 + 12.0 * __builtin_popcountll(~d.o2_far & all_o2);
+      for (int k = 0; k < t.n_h2o; ++k) {
+        if (!(t.h2o_w2[k] > 0.0)) continue;
+        const double c = t.h2o_fl[k];
+        const double dist = (c < frq[b]) ? frq[b] - c : ((c > frq[e]) ? c - frq[e] : 0.0);
+        per_f += 50.0 * std::max(0.0, 1.0 - dist / (10.0 * sd_halfwidth_bound(t, k)));
+      }
+      return per_f * (e - b + 1);
+    };
+    std::stable_sort(spans.begin(), spans.end(), [&](const Span& x, const Span& y) { return cost(x) > cost(y); });
   }
   // Lagrange weights of the half-sampled speed-dependent shape, per chunk (zero for a partial last chunk: never used)
   ws->lag_sd.assign((size_t)nchunks * SD_TARGETS * SD_NODES, 0.0);
