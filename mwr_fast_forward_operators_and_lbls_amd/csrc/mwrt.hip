@@ -370,7 +370,9 @@ void chunk_masks(const mwrt_model_desc& t, const double* frq, int nf, int nfc, s
       const double dist = (lm.vf_u0 < plo) ? plo - lm.vf_u0 : ((lm.vf_u0 > phi) ? lm.vf_u0 - phi : 0.0);
       return lm.vf_h <= VF_RATIO_MAX * dist;
     };
-    static const bool no_vfar = std::getenv("MWRT_NO_VFAR") != nullptr;                   // diagnostic: time the direct sums
+    // (a line costs ~40 instructions in the polynomial against 7 per frequency directly: not worth it under 7 frequencies)
+    static const bool no_vfar_env = std::getenv("MWRT_NO_VFAR") != nullptr;               // diagnostic: time the direct sums
+    const bool no_vfar = no_vfar_env || (j1 - j0) < VF_MIN_FREQS;
     for (int k = 0; k < t.n_o2; ++k) {
       double dmin = 1e300;
       for (int j = j0; j < j1; ++j) dmin = std::min(dmin, std::fabs(frq[j] - t.o2_f[k]));

@@ -558,6 +558,7 @@ __device__ __forceinline__ void far_quad_accumulate(const double* sfq, const Far
 // the lines (chunk_masks) with the shift / width allowances.
 constexpr int VF_TERMS = 8;
 constexpr double VF_RATIO_MAX = 0.016;
+constexpr int VF_MIN_FREQS = 7;              // ... and chunks with fewer frequencies than this are served directly
 constexpr int VF_MIN_LINES = 4;              // fewer lines than this do not pay for the Horner pass (8 per frequency)
 __device__ __forceinline__ void vfar_add(const FarLine& fl, double u0, double h, double (&acc)[VF_TERMS]) {
   const double d0 = __builtin_fma(u0, u0 + fl.A2, fl.Bc);

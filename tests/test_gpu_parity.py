@@ -1096,8 +1096,8 @@ def test_very_far_line_sets(gpu_ctx, name, band):
     band, the 22- and 118-GHz lines).  Absorption against the oracle to 2e-11 relative, TBs to the usual bar."""
     frq = {"hatpro": pr.HATPRO_FRQS,
            "g-band": np.array([175.31, 178.31, 180.31, 181.31, 182.31, 184.31, 186.31, 190.31]),
-           "w-band": np.array([89.0, 89.5, 90.0, 90.5, 91.0, 91.5]),
-           "340": np.array([338.0, 339.0, 340.0, 341.0, 342.0, 343.0])}[band]
+           "w-band": np.array([89.0, 89.5, 90.0, 90.5, 91.0, 91.5, 92.0]),
+           "340": np.array([339.0, 339.5, 340.0, 340.5, 341.0, 341.5, 342.0])}[band]          # (sets need >= 7 frequencies)
     P = pr.synthetic_profiles(4, 77)
     m = sp.get_model(name)
     aw_g, ad_g = gpu_ctx.absorption_batch(name, P["p"], P["t"], P["rh"], frq)
