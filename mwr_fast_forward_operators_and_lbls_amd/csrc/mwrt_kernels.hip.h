@@ -62,7 +62,7 @@ __device__ __forceinline__ int div_small(int n, int d, unsigned magic) {
 #endif
 // timing-only ablation builds (tools/ablate.sh): bit 1 skips the O2 line loop, 2 the H2O Lorentz
 // loop, 4 the speed-dependent loop, 8 the K2 integration, 16 the layer step of the TAU absorption kernels, 32 their
-// stores.  Always 0 in the shipped library.
+// stores, 64 the scalar loads of their interpolation weights.  Always 0 in the shipped library.
 #ifndef MWRT_ABLATE
 #define MWRT_ABLATE 0
 #endif
@@ -2254,7 +2254,7 @@ k_absorb_win(const AbsorbWinArgs A) {
     for (int m = 0; m < nn; ++m) {                            // one node per trip: 16 scalar weights live at a time
       const double sm = S_l[m * nthreads + tid];
 #pragma unroll
-      for (int j = 0; j < NFC; ++j) out[j] = __builtin_fma(Lt[m * NFC + j], sm, out[j]);
+      for (int j = 0; j < NFC; ++j) out[j] = __builtin_fma((MWRT_ABLATE & 64) ? 0.0625 + 0.001 * j : Lt[m * NFC + j], sm, out[j]);
     }
   };
 
