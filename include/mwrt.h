@@ -66,7 +66,7 @@
 extern "C" {
 #endif
 
-#define MWRT_VERSION 300          /* 0.3.0: layer-optical-depth two-kernel form (mwrt_layer_tau_*, mwrt_tb_from_layer_tau_device) */
+#define MWRT_VERSION 301          /* 0.3.1: + mwrt_set_chunk_width; 0.3.0: layer-optical-depth two-kernel form (mwrt_layer_tau_*, mwrt_tb_from_layer_tau_device) */
 #define MWRT_MAX_H2O_LINES 32
 #define MWRT_MAX_O2_LINES 64
 #define MWRT_MAX_X_LINES 64       /* lines of the extra trace species (ozone) */
@@ -239,6 +239,14 @@ int mwrt_absorption_batch_device(mwrt_context* ctx, const mwrt_model* model,
                                  const double* d_p_hpa, const double* d_t_k, const double* d_rh_frac,
                                  int32_t nf, const double* frq_ghz,
                                  double* d_awet_out, double* d_adry_out, void* stream);
+
+/* Frequencies per workgroup of the fused TB kernel: 0 = automatic (default), or 8 / 14 / 16.  Automatic: 14 for channel lists
+ * that are a multiple of 14 (the HATPRO list: one workgroup per profile, every per-(level, line) quantity computed once), 16
+ * otherwise, whatever the batch size -- so a profile's results do not depend on the batch it arrives in, bit for bit.
+ * 8 is the latency setting for small batches: two workgroups per 14-channel profile (MI355X, seven elevations: one profile
+ * 58 instead of 75 us, 256 profiles 61 instead of 76, 512 profiles 77 instead of 83; slower from ~600 profiles up).  The width
+ * changes the grouping of the line sums, so results move by ~1e-13 relative between widths. */
+int mwrt_set_chunk_width(mwrt_context* ctx, int width);
 
 /* How a fine spectral grid is evaluated: 0 = automatic (windowed when the frequency list qualifies: >= 128 strictly
  * increasing frequencies whose 128-frequency windows each span <= 6 GHz, <= 505 levels, LDS permitting), 1 = always every

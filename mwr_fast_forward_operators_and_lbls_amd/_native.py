@@ -42,7 +42,7 @@ class MwrtTbOptions(ctypes.Structure):
                 ("reserved0", ctypes.c_int32), ("o3n", ctypes.c_void_p)]
 
 
-MWRT_VERSION = 300
+MWRT_VERSION = 301
 
 
 #: every symbol include/mwrt.h declares: (name, restype, argtypes)
@@ -80,6 +80,7 @@ SIGNATURES = {
     "mwrt_tb_jacobian_batch": (ctypes.c_int, [_vp, _vp, _i64, _i32, _vp, _vp, _vp, _vp, _i32, _vp, _i32, _vp, _vp, _vp, _vp,
                                               _vp, _vp]),
     "mwrt_set_absorption_mode": (ctypes.c_int, [_vp, ctypes.c_int]),
+    "mwrt_set_chunk_width": (ctypes.c_int, [_vp, ctypes.c_int]),
     "mwrt_selftest_math": (ctypes.c_int, [_vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp]),
     "mwrt_synchronize": (ctypes.c_int, [_vp, _vp]),
     "mwrt_set_timing": (ctypes.c_int, [_vp, ctypes.c_int]),
@@ -402,6 +403,10 @@ class Context:
             _ptr(frq), elev.size, _ptr(elev), _ptr(d_valid), _ptr(d_tb), _stream(stream)), "mwrt_tb_from_layer_tau_device")
 
     @_serialised
+    def set_chunk_width(self, width: int):
+        """Frequencies per workgroup of the fused TB kernel: 0 automatic, 8 / 14 / 16 (include/mwrt.h)."""
+        self._check(self._lib.mwrt_set_chunk_width(self._handle, int(width)), "mwrt_set_chunk_width")
+
     def set_absorption_mode(self, mode: int):
         """0 automatic, 1 every line at every frequency, 2 windowed (fine grids; include/mwrt.h)."""
         self._check(self._lib.mwrt_set_absorption_mode(self._handle, int(mode)), "mwrt_set_absorption_mode")

@@ -90,12 +90,14 @@ struct mwrt_context {
   int device = 0;
   hipStream_t stream = nullptr;
   int lds_max = 65536;
+  int num_cus = 256;            // compute units of the device (MI355X: 256)
   // small per-call parameter arrays (frq, airmass): content-keyed device copies.  A copy is never
   // overwritten or freed while the context lives (bar LRU eviction behind a device-wide drain), so
   // launches still queued on ANY stream and captured hipGraphs keep reading valid memory.
   ParamCache frq_cache, am_cache, elev_cache;
   // fine-grid absorption: window descriptors + Lagrange matrices per (model, frequency list), immutable like ParamCache
   int absorption_mode = 0;      // 0 auto, 1 direct, 2 windowed
+  int chunk_width = 0;          // 0 auto, 8 / 14 / 16: frequencies per workgroup of the fused TB kernel (mwrt_set_chunk_width)
   struct WinEntry { uint64_t model_id; std::vector<double> frq; char* d_blob; size_t off_lag, off_lagh, off_lagsd; int nwin; };
   std::vector<WinEntry> win_cache;
   // line classification of every frequency chunk (LineMasks), per (model, frequency list, chunk width): depends on the
@@ -316,9 +318,12 @@ int pick_nfc(int nf) {
   return 16;
 }
 
-// ... unless the profile is so tall that the wide chunk's LDS rows do not fit: then 8
+// ... unless the caller fixed the width (mwrt_set_chunk_width: 8 splits a 14-channel profile over two workgroups, each with
+// the full per-(level, line) set-up but half the line-frequency work -- one profile 58 instead of 75 us, 256 profiles 61
+// instead of 76, 512 profiles 77 instead of 83 at seven elevations; not the default because results would then depend, in the
+// 13th digit, on how a caller batches its profiles) or the profile is so tall that the wide chunk's LDS rows do not fit: then 8
 int pick_nfc_fused(const mwrt_context* c, int nlev, int nf, int nang) {
-  int nfc = pick_nfc(nf);
+  int nfc = c->chunk_width ? c->chunk_width : pick_nfc(nf);
   LaunchGeom g; size_t lds;
   if (!plan_fused(c, nfc, nlev, nf, nang, &g, &lds)) nfc = 8;
   return nfc;
@@ -403,11 +408,17 @@ void chunk_masks(const mwrt_model_desc& t, const double* frq, int nf, int nfc, s
 
 // device copy of chunk_masks(...), immutable and cached like the window descriptors
 int get_masks(mwrt_context* c, const mwrt_model* m, const double* frq, int nf, int nfc, const LineMasks** out) {
-  for (auto& e : c->mask_cache)
+  for (size_t i = 0; i < c->mask_cache.size(); ++i) {
+    auto& e = c->mask_cache[i];
     if (e.model_id == m->id && e.nfc == nfc && (int)e.frq.size() == nf && std::memcmp(e.frq.data(), frq, sizeof(double) * nf) == 0) {
-      *out = e.d_masks; return MWRT_OK;
+      *out = e.d_masks;
+      // least recently USED goes first: a hit moves to the back, so a warm-up call keeps what it touched (a later miss of the
+      // same sequence must not evict it -- the eviction drains the device, which a capturing stream refuses)
+      std::rotate(c->mask_cache.begin() + (long)i, c->mask_cache.begin() + (long)i + 1, c->mask_cache.end());
+      return MWRT_OK;
     }
-  if (c->mask_cache.size() >= 64) {                     // bounded: drop the oldest entry behind a device-wide drain
+  }
+  if (c->mask_cache.size() >= 64) {                     // bounded: drop the least recently used entry behind a device-wide drain
     HIP_TRY(hipDeviceSynchronize());
     (void)hipFree(c->mask_cache.front().d_masks);
     c->mask_cache.erase(c->mask_cache.begin());
@@ -567,13 +578,16 @@ void build_windows(const mwrt_model_desc& t, const double* frq, int nf, WindowSe
 struct WinPtrs { const WinDesc* win; const double* lag; const double* lag_h; const double* lag_sd; const LineMasks* masks; int nwin; };   // masks: get_masks(.., WIN_NFC)
 
 int get_windows(mwrt_context* c, const mwrt_model* m, const double* frq, int nf, WinPtrs* out) {
-  for (auto& e : c->win_cache)
+  for (size_t i = 0; i < c->win_cache.size(); ++i) {
+    auto& e = c->win_cache[i];
     if (e.model_id == m->id && (int)e.frq.size() == nf && std::memcmp(e.frq.data(), frq, sizeof(double) * nf) == 0) {
       *out = WinPtrs{(const WinDesc*)e.d_blob, (const double*)(e.d_blob + e.off_lag), (const double*)(e.d_blob + e.off_lagh),
                      (const double*)(e.d_blob + e.off_lagsd), nullptr, e.nwin};
+      std::rotate(c->win_cache.begin() + (long)i, c->win_cache.begin() + (long)i + 1, c->win_cache.end());   // least recently used first
       return get_masks(c, m, frq, nf, WIN_NFC, &out->masks);
     }
-  if (c->win_cache.size() >= 16) {                      // bounded: drop the oldest entry behind a device-wide drain
+  }
+  if (c->win_cache.size() >= 16) {                      // bounded: drop the least recently used entry behind a device-wide drain
     HIP_TRY(hipDeviceSynchronize());
     (void)hipFree(c->win_cache.front().d_blob);
     c->win_cache.erase(c->win_cache.begin());
@@ -716,6 +730,8 @@ int mwrt_create(int device_id, mwrt_context** out) {
   int lds = 0;
   if (hipDeviceGetAttribute(&lds, hipDeviceAttributeMaxSharedMemoryPerBlock, device_id) == hipSuccess && lds > 0)
     c->lds_max = lds;
+  int cus = 0;
+  if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device_id) == hipSuccess && cus > 0) c->num_cus = cus;
   if (const char* mb = std::getenv("MWRT_ALPHA_BATCH_MB")) {       // diagnostic: size of a fine-grid profile batch
     const long v = std::atol(mb);
     if (v > 0) c->alpha_batch_bytes = (size_t)v << 20;
@@ -1269,6 +1285,13 @@ int mwrt_tb_jacobian_batch(mwrt_context* c, const mwrt_model* m, int64_t nprof, 
     for (size_t k = 0; k < (size_t)nang * nf; ++k) tb[o + k] = qnan;
     for (size_t k = 0; k < (size_t)nang * nf * nlev; ++k) { dtb_dt[o * nlev + k] = qnan; dtb_de[o * nlev + k] = qnan; dtb_ddz[o * nlev + k] = qnan; }
   }
+  return MWRT_OK;
+}
+
+int mwrt_set_chunk_width(mwrt_context* c, int width) {
+  if (!c) return fail(MWRT_ERR_INVALID_ARGUMENT, "null context");
+  if (width != 0 && width != 8 && width != 14 && width != 16) return fail(MWRT_ERR_INVALID_ARGUMENT, "chunk width: 0 (automatic), 8, 14 or 16");
+  c->chunk_width = width;
   return MWRT_OK;
 }
 

@@ -30,7 +30,7 @@ def test_library_exports_every_declared_symbol(native_lib):
 
 
 def test_version_and_struct_layout(native_lib):
-    assert native_lib.mwrt_version() == 300 == _native.MWRT_VERSION
+    assert native_lib.mwrt_version() == 301 == _native.MWRT_VERSION
     assert native_lib.mwrt_model_desc_size() == ctypes.sizeof(sp.MwrtModelDesc)
     c = sp.get_model("R24").to_c()
     assert c.n_o2 == 49 and c.n_h2o == 16 and c.liq_mode == 1 and sp.get_model("R98").to_c().liq_mode == 0

@@ -24,10 +24,20 @@ def oracle_tb(m, P, i, frq, ang):
     return {k: r[k].reshape(len(ang), len(frq)) for k in ("tbtotal", "tbatm", "tmr", "tauwet", "taudry")}, r["taulay"]
 
 
+@pytest.fixture
+def chunk_width(gpu_ctx, request):
+    """Pins the fused kernel's chunk width for one test (0 = automatic: 14 for the HATPRO list, the instantiation the headline
+    shape runs; 8 = the small-batch latency setting, two workgroups per profile) and restores the automatic choice afterwards."""
+    gpu_ctx.set_chunk_width(request.param)
+    yield request.param
+    gpu_ctx.set_chunk_width(0)
+
+
 @pytest.mark.parametrize("name", MODELS)
 @pytest.mark.parametrize("ang", [np.array([90.0]), pr.BENCH_ELEVATIONS_7, pr.REFERENCE_ELEVATIONS],
                          ids=["zenith", "7elev", "10elev"])
-def test_tb_matches_oracle(gpu_ctx, name, ang):
+@pytest.mark.parametrize("chunk_width", [0, 8], indirect=True, ids=["auto", "w8"])
+def test_tb_matches_oracle(gpu_ctx, name, ang, chunk_width):
     P = pr.synthetic_profiles(5, 21)
     frq = pr.HATPRO_FRQS
     tb, valid, ex = gpu_ctx.tb_batch(name, P["z"], P["p"], P["t"], P["rh"], frq, ang, extras=True)
@@ -45,7 +55,8 @@ def test_tb_matches_oracle(gpu_ctx, name, ang):
 
 
 @pytest.mark.parametrize("name", GOLDEN_MODELS)
-def test_golden_vectors(gpu_ctx, name):
+@pytest.mark.parametrize("chunk_width", [0, 8], indirect=True, ids=["auto", "w8"])
+def test_golden_vectors(gpu_ctx, name, chunk_width):
     with np.load(GOLD, allow_pickle=False) as f:
         g = {k: f[k] for k in f.files}
     tb, valid, ex = gpu_ctx.tb_batch(name, g["z"], g["p"], g["t"], g["rh"], g["frq"], g["ang"], extras=True)
@@ -61,7 +72,8 @@ def test_golden_vectors(gpu_ctx, name):
 
 
 @pytest.mark.parametrize("nf", [1, 7, 8, 9, 14, 15, 16, 17, 28, 33])
-def test_frequency_chunking(gpu_ctx, nf):
+@pytest.mark.parametrize("chunk_width", [0, 8, 14, 16], indirect=True, ids=["auto", "w8", "w14", "w16"])
+def test_frequency_chunking(gpu_ctx, nf, chunk_width):
     """Every chunk width (8 / 14 / 16 lanes of accumulators) and ragged tails agree with the oracle."""
     P = pr.synthetic_profiles(2, 22, nlev=60)
     frq = np.linspace(20.0, 60.0, nf) if nf > 1 else np.array([31.4])
@@ -75,7 +87,8 @@ def test_frequency_chunking(gpu_ctx, nf):
 
 
 @pytest.mark.parametrize("nlev", [20, 63, 64, 65, 128, 192, 256, 257, 600, 1024])
-def test_level_counts(gpu_ctx, nlev):
+@pytest.mark.parametrize("chunk_width", [0, 8], indirect=True, ids=["auto", "w8"])
+def test_level_counts(gpu_ctx, nlev, chunk_width):
     """Ragged level counts across the wave (64) and launch-bound (256 / 1024) edges."""
     P = pr.synthetic_profiles(3, 23, nlev=nlev)
     ang = np.array([90.0, 30.0, 5.4])
@@ -567,6 +580,11 @@ def test_argument_validation(gpu_ctx):
         assert ei.value.code == -1 and "elevation" in str(ei.value)
     tb, _ = gpu_ctx.tb_batch("R24", P["z"], P["p"], P["t"], P["rh"], pr.HATPRO_FRQS, np.array([30.0, 150.0]))
     assert np.allclose(tb[:, 0], tb[:, 1], rtol=0, atol=1e-9)           # sin(150 deg) = sin(30 deg)
+    for bad in (-1, 4, 12, 32):
+        with pytest.raises(MwrtError) as ei:
+            gpu_ctx.set_chunk_width(bad)
+        assert ei.value.code == -1
+    gpu_ctx.set_chunk_width(0)
     with pytest.raises(ValueError):
         gpu_ctx.tb_batch("R24", P["z"], P["p"][:, :-1], P["t"], P["rh"], pr.HATPRO_FRQS, np.array([90.0]))
     lib = gpu_ctx._lib

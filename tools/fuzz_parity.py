@@ -46,6 +46,7 @@ while time.time() < t_end and (max_calls is None or cases < max_calls):
     ang = np.sort(rng.uniform(2.0, 90.0, nang))[::-1].copy()
     if rng.random() < 0.3: ang[0] = 90.0
     nan_k = int(rng.integers(0, nang)) if (nang > 1 and rng.random() < 0.15) else -1
+    ctx.set_chunk_width(int(rng.choice([0, 0, 8, 14, 16])))      # automatic (small batches: 8) or a pinned instantiation
     fk = rng.integers(0, 4)
     if fk == 0: frq = pr.HATPRO_FRQS
     elif fk == 1: frq = np.sort(rng.uniform(10.0, 200.0, int(rng.integers(1, 41))))
