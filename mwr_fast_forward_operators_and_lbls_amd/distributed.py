@@ -108,8 +108,8 @@ class GatherRing:
 
     ``out`` is this rank's ring ``[slots, ...]``; ``gathered`` ``[world, slots, ...]`` receives every rank's ring.
     ``run(step, n)`` calls ``step(s)`` for s = 0 .. n-1 (it must write ``out[s % slots]``) and gathers finished
-    slots ``bucket`` at a time; the bucket is cut one step before the end so that the gather left exposed after the
-    last step carries a single batch, and before the ring wraps everything in flight is drained (the slots about to
+    slots ``bucket`` at a time; the buckets shrink towards the end (cuts after steps n-4, n-2, n-1) so that the gather left
+    exposed after the last step carries a single batch, and before the ring wraps everything in flight is drained (the slots about to
     be overwritten must have left).  Every batch is gathered -- none is skipped.
 
     On GPUs the steps run on ``compute_stream`` and each gather on ``comm_stream`` behind an event, so it overlaps
@@ -170,9 +170,10 @@ class GatherRing:
             step(s)
             if mark_last is not None and s == n - 1:
                 mark_last.record(self.compute_stream)
-            # ... and the bucket is cut one step before the end, so that the only gather left exposed after the
+            # ... and the buckets shrink towards the end -- cuts after steps n-4, n-2 and n-1 -- so that each of the last
+            # gathers has about as many steps to hide under as it carries batches, and the only one left exposed after the
             # last step carries a single batch
-            if self.collective and (slot + 1 - pending == bucket or slot == slots - 1 or s >= n - 2):
+            if self.collective and (slot + 1 - pending == bucket or slot == slots - 1 or s >= n - 2 or s == n - 4):
                 self.gather_slots(pending, slot + 1)
                 pending = slot + 1
         if self.collective:
