@@ -140,3 +140,40 @@ def test_gather_ring_single_process_without_collective():
     calls = []
     ring.run(lambda s: calls.append(s), 11)
     assert calls == list(range(11)) and ring.gathers == 0
+
+
+def test_gather_ring_bucket_schedule():
+    """Which slots each collective carries: regular buckets, then shrinking ones (cuts after steps n-4, n-2, n-1) so that the
+    gather left exposed after the last step is a single batch; a ring wrap drains and starts over.  No process group: the
+    collective itself is replaced by a recorder."""
+    import torch
+    from mwr_fast_forward_operators_and_lbls_amd.distributed import GatherRing
+
+    class Recorder(GatherRing):
+        def __init__(self, slots, bucket):
+            super().__init__(torch.zeros((slots, 1)), torch.zeros((1, slots, 1)), bucket)
+            self.ranges = []
+
+        def gather_slots(self, b0, b1):
+            self.ranges.append((b0, b1))
+            self.gathers += 1
+
+        def drain(self):
+            pass
+
+    r = Recorder(256, 5)
+    r.run(lambda s: None, 20)
+    assert r.ranges == [(0, 5), (5, 10), (10, 15), (15, 17), (17, 19), (19, 20)]
+    r = Recorder(256, 5)
+    r.run(lambda s: None, 3)
+    assert r.ranges == [(0, 2), (2, 3)]
+    r = Recorder(256, 5)
+    r.run(lambda s: None, 1)
+    assert r.ranges == [(0, 1)]
+    r = Recorder(8, 3)                                   # ring of 8 slots, 20 steps: wraps after 8 and 16
+    r.run(lambda s: None, 20)
+    covered = []
+    for b0, b1 in r.ranges:
+        covered += list(range(b0, b1))
+    assert covered == [s % 8 for s in range(20)]         # every batch gathered once, in order, none across a wrap
+    assert r.ranges[-1] == (3, 4) and r.ranges[-2] == (1, 3)
