@@ -872,7 +872,6 @@ __device__ __forceinline__ void h2o_absorb(cmodel M, const LevelState& L, const 
           double dn[SD_NODES];
 #pragma unroll
           for (int n = 0; n < SD_NODES; ++n) {
-            constexpr int dummy = 0; (void)dummy;
             const int j = sd_node_slot(n);
             const double d1 = sfq[2 * j] - q.c1;
             const double sdre = sd_shape(d1);
